@@ -1,0 +1,502 @@
+// HBM-bound elementwise / reduction kernels of the crosslayer-transcoder training step (gfx950).
+// One pass over each [B, L*F] or [B, L*d] tensor per kernel; every reduction is two-stage and
+// fixed-order, so results are bitwise reproducible run to run.
+#include <math.h>
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+inline int col_chunks(int rows) { int c = (rows + 63) / 64; return c < 1 ? 1 : (c > 32 ? 32 : c); }
+inline int blocks_for(long count, int per_block, int cap = 8192) {
+    long b = (count + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- K1 -------------------------------------------------------------------------------------
+__global__ void column_stats_kernel(const float* __restrict__ x, long rs, int rows, int n, float* __restrict__ mean,
+                                    float* __restrict__ stdv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)x[(long)r * rs + j];
+    const double mu = s / rows;
+    double q = 0.0;
+    for (int r = 0; r < rows; ++r) { const double dlt = (double)x[(long)r * rs + j] - mu; q += dlt * dlt; }
+    // torch.std: unbiased (N-1); a single row gives nan in torch, as here (0/0)
+    const float sd = (float)sqrt(q / (double)(rows - 1));
+    mean[j] = (float)mu;
+    stdv[j] = sd < 1e-8f ? 1e-8f : sd;    // clamp_(min=1e-8); nan stays nan as in torch.clamp
+}
+
+template <bool VEC>
+__global__ void standardize_kernel(const float* __restrict__ x, long rs, const float* __restrict__ mean,
+                                   const float* __restrict__ stdv, int rows, int n, float* __restrict__ o32,
+                                   uint16_t* __restrict__ o16) {
+    constexpr int W = VEC ? 4 : 1;
+    const int nq = n / W;
+    const long total = (long)rows * nq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nq), j = (int)(i - (long)r * nq) * W;
+        float v[W];
+        if (VEC) {
+            const float4 a = *reinterpret_cast<const float4*>(x + (long)r * rs + j);
+            const float4 m = *reinterpret_cast<const float4*>(mean + j);
+            const float4 s = *reinterpret_cast<const float4*>(stdv + j);
+            v[0] = (a.x - m.x) / s.x; v[1 % W] = (a.y - m.y) / s.y; v[2 % W] = (a.z - m.z) / s.z; v[3 % W] = (a.w - m.w) / s.w;
+        } else {
+            v[0] = (x[(long)r * rs + j] - mean[j]) / stdv[j];
+        }
+        const long o = (long)r * n + j;
+        if (o32) {
+            if (VEC) *reinterpret_cast<float4*>(o32 + o) = make_float4(v[0], v[1 % W], v[2 % W], v[3 % W]);
+            else o32[o] = v[0];
+        }
+        if (o16) {
+            if (VEC) {
+                ushort4 h; h.x = f32_to_bf16(v[0]); h.y = f32_to_bf16(v[1 % W]); h.z = f32_to_bf16(v[2 % W]); h.w = f32_to_bf16(v[3 % W]);
+                *reinterpret_cast<ushort4*>(o16 + o) = h;
+            } else o16[o] = f32_to_bf16(v[0]);
+        }
+    }
+}
+
+__global__ void destandardize_kernel(const float* __restrict__ r, const float* __restrict__ mean,
+                                     const float* __restrict__ stdv, long total, int n, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % n);
+        out[i] = r[i] * stdv[j] + mean[j];
+    }
+}
+
+// ---- K3 -------------------------------------------------------------------------------------
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ o, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        o[i] = v > 0.0f ? v : (v != v ? v : 0.0f);
+    }
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = x[i] > 0.0f ? g[i] : 0.0f;
+}
+__global__ void mask_positive_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = f[i] > 0.0f ? g[i] : 0.0f;
+}
+__global__ void jumprelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ theta, float* __restrict__ o,
+                                    long total, int n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        o[i] = (v > theta[i % n] && v > 0.0f) ? v : v * 0.0f;   // mask * input (keeps nan/inf semantics)
+    }
+}
+
+__device__ __forceinline__ float rect_window(float x, float th, float bw) {
+    const float u = (x - th) / bw;                         // jumprelu.py:9-14, 47
+    return ((u + 0.5f > 0.0f) ? 1.0f : 0.0f) - ((u - 0.5f > 0.0f) ? 1.0f : 0.0f);
+}
+
+// grid: (ceil(n/256), chunks).  Each thread owns one column j and a contiguous chunk of rows.
+__global__ void jumprelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ theta, float bw,
+                                    const float* __restrict__ g, float* __restrict__ dx, float* __restrict__ part,
+                                    int rows, int n, int rows_per_chunk) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    const float th = theta[j], coef = -(th / bw);
+    float acc = 0.0f;
+    for (int r = r0; r < r1; ++r) {
+        const long i = (long)r * n + j;
+        const float v = x[i], gg = g[i];
+        dx[i] = v < 0.0f ? 0.0f : gg;
+        acc += coef * rect_window(v, th, bw) * gg;
+    }
+    part[(long)blockIdx.y * n + j] = acc;
+}
+
+__global__ void reduce_cols_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ out, int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += part[(long)c * n + j];
+    out[j] = accumulate ? out[j] + s : s;
+}
+
+__global__ void column_sum_kernel(const float* __restrict__ x, float* __restrict__ part, int rows, int n, int rows_per_chunk) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float acc = 0.0f;
+    for (int r = r0; r < r1; ++r) acc += x[(long)r * n + j];
+    part[(long)blockIdx.y * n + j] = acc;
+}
+
+// sums nb x k block partials (double) in block order; one block of 64 threads per output.
+__global__ void reduce_partials_kernel(const double* __restrict__ part, int nb, int k, double* __restrict__ out) {
+    const int o = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) s += part[(long)b * k + o];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[o] = s;
+}
+
+// ---- K8 -------------------------------------------------------------------------------------
+__global__ void mse_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs, const float* __restrict__ mean,
+                           const float* __restrict__ stdv, int rows, int n, float gs, float* __restrict__ g,
+                           float* __restrict__ ys_out, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const long total = (long)rows * n;
+    double acc = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int rr = (int)(i / n), j = (int)(i - (long)rr * n);
+        const float ys = (y[(long)rr * yrs + j] - mean[j]) / stdv[j];
+        const float dlt = r[i] - ys;
+        if (g) g[i] = gs * dlt;
+        if (ys_out) ys_out[i] = ys;
+        acc += (double)(dlt * dlt);
+    }
+    const double s = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void aux_mse_kernel(const float* __restrict__ ar, const float* __restrict__ ys, const float* __restrict__ r,
+                               long total, float gs, float* __restrict__ ga, float* __restrict__ gm,
+                               double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float e = ar[i] - (ys[i] - r[i]);
+        const float e2 = e * e;
+        const bool fin = isfinite(e2);
+        // nan_to_num(e2, 0.0): nan -> 0, +inf -> FLT_MAX; its backward passes grad only where finite
+        acc += (e2 != e2) ? 0.0 : (fin ? (double)e2 : (double)3.4028234663852886e38f);
+        const float gv = fin ? gs * e : 0.0f;
+        ga[i] = gv;
+        gm[i] += gv;
+    }
+    const double s = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// ---- K9 / K10 ---------------------------------------------------------------------------------
+// one wave per row
+__global__ void row_sqnorm_kernel(const float* __restrict__ W, int rows, int d, float* __restrict__ sq, int accumulate) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = W + (long)row * d;
+    float s = 0.0f;
+    for (int j = lane; j < d; j += 64) { const float v = p[j]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) sq[row] = accumulate ? sq[row] + s : s;
+}
+
+__global__ void rowscale_add_kernel(const float* __restrict__ W, const float* __restrict__ dnorm, const float* __restrict__ sq,
+                                    float* __restrict__ dW, int rows, int d) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float coef = dnorm[row] / sqrtf(sq[row]);
+    const long o = (long)row * d;
+    for (int j = lane; j < d; j += 64) dW[o + j] += coef * W[o + j];
+}
+
+// grid: (ceil(n/256), chunks); part layout: [2][chunks][n] floats then [nblocks][3] doubles
+__global__ void jumprelu_loss_kernel(const float* __restrict__ x, const float* __restrict__ theta, const float* __restrict__ sq,
+                                     const float* __restrict__ dfm, float bw, float lamB, float c, int use_tanh,
+                                     float coefBL, float* __restrict__ dpre, float* __restrict__ part_th,
+                                     float* __restrict__ part_dn, double* __restrict__ part_s, int rows, int n,
+                                     int rows_per_chunk) {
+    __shared__ double sh[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double s_t = 0.0, s_p = 0.0, s_w = 0.0;
+    if (j < n) {
+        const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+        const float th = theta[j], nrm = sqrtf(sq[j]), thc = -(th / bw);
+        float a_th = 0.0f, a_dn = 0.0f;
+        for (int r = r0; r < r1; ++r) {
+            const long i = (long)r * n + j;
+            const float v = x[i];
+            const float f = (v > th && v > 0.0f) ? v : 0.0f;
+            const float w = f * nrm * c;
+            const float t = use_tanh ? tanhf(w) : w;
+            const float dt = use_tanh ? (1.0f - t * t) : 1.0f;
+            s_t += (double)t; s_w += (double)w;
+            s_p += (double)(v < 0.0f ? -v : 0.0f);
+            if (dfm) {
+                const float df = dfm[i] + lamB * dt * c * nrm;
+                dpre[i] = (v < 0.0f ? 0.0f : df) - (v < 0.0f ? coefBL : 0.0f);
+                a_th += thc * rect_window(v, th, bw) * df;
+                a_dn += lamB * dt * c * f;
+            }
+        }
+        if (dfm) { part_th[(long)blockIdx.y * n + j] = a_th; part_dn[(long)blockIdx.y * n + j] = a_dn; }
+    }
+    const long b = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    double s;
+    s = block_sum_d(s_t, sh); if (threadIdx.x == 0) part_s[b * 3 + 0] = s;
+    s = block_sum_d(s_p, sh); if (threadIdx.x == 0) part_s[b * 3 + 1] = s;
+    s = block_sum_d(s_w, sh); if (threadIdx.x == 0) part_s[b * 3 + 2] = s;
+}
+
+// ---- K12 --------------------------------------------------------------------------------------
+__global__ void column_any_positive_kernel(const float* __restrict__ f, int rows, int n, uint8_t* __restrict__ fired) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = j < n;
+    bool hit = false;
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+        if (in && !hit) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (r0 + u < rows) hit |= f[(long)(r0 + u) * n + j] > 0.0f;
+        }
+        if (__all(hit || !in)) break;
+    }
+    if (in) fired[j] = hit ? 1 : 0;
+}
+
+__global__ void dead_update_kernel(const uint8_t* __restrict__ fired, int n, long add, int64_t* __restrict__ la, long ttd,
+                                   uint8_t* __restrict__ dead, int32_t* __restrict__ dead_count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int dflag = 0;
+    if (j < n) {
+        const int64_t v = (fired[j] ? 0 : la[j]) + add;
+        la[j] = v;
+        dflag = v > ttd ? 1 : 0;
+        dead[j] = (uint8_t)dflag;
+    }
+    const unsigned long long m = __ballot(dflag);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(dead_count, __popcll(m));   // integer: order-independent
+}
+
+__global__ void mask_dead_kernel(const float* __restrict__ x, const uint8_t* __restrict__ dead, float* __restrict__ o,
+                                 long total, int n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        o[i] = dead[i % n] ? x[i] : -INFINITY;
+}
+
+__global__ void threshold_fwd_kernel(const float* __restrict__ x, const float* __restrict__ thr, int per_layer,
+                                     float* __restrict__ o, long total, int L, int F) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int l = per_layer ? (int)((i / F) % L) : 0;
+        const float t = fmaxf(thr[l], 0.0f), v = x[i];
+        o[i] = v > t ? v : 0.0f;
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(in[i]);
+}
+
+// 64x64 tile transpose through LDS: in [rows][cols] (ld_in) -> out [cols][rows] (ld_out), bf16
+__global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, uint16_t* __restrict__ out, long ldo, int rows,
+                                      int cols, long s_in, long s_out) {
+    __shared__ float tile[64][65];
+    in += blockIdx.z * s_in; out += blockIdx.z * s_out;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(long)(r0 + r) * ldi + c0 + tx] : 0.0f;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = f32_to_bf16(tile[tx][c]);
+}
+
+// ---- K13 --------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n4, long n, float lr, float b1, float b2, float eps, float wd, int adamw,
+                            float step_size, float inv_sqrt_bc2, uint16_t* __restrict__ sh) {
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
+        mm = mm + (gg - mm) * (1.0f - b1);
+        vv = vv * b2 + (1.0f - b2) * gg * gg;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        pp -= step_size * (mm / denom);
+    };
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+        if (sh) { ushort4 h; h.x = f32_to_bf16(P.x); h.y = f32_to_bf16(P.y); h.z = f32_to_bf16(P.z); h.w = f32_to_bf16(P.w);
+                  reinterpret_cast<ushort4*>(sh)[i] = h; }
+    }
+    for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+        float P = p[i], M = m[i], V = v[i];
+        upd(P, g[i], M, V);
+        p[i] = P; m[i] = M; v[i] = V;
+        if (sh) sh[i] = f32_to_bf16(P);
+    }
+}
+}  // namespace
+
+// =============================================== C ABI ===============================================
+extern "C" {
+const char* clt_arch(void) { return "gfx950"; }
+int clt_abi_version(void) { return 1; }
+
+int clt_column_stats_f32(const float* x, long rs, int rows, int n, float* mean, float* stdv, void* st) {
+    if (rows <= 0 || n <= 0 || rs < n) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(column_stats_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(st), x, rs, rows, n, mean, stdv);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_standardize_f32(const float* x, long rs, const float* mean, const float* stdv, int rows, int n, float* o32,
+                        uint16_t* o16, void* st) {
+    if (rows <= 0 || n <= 0 || rs < n) return CLT_ERR_SHAPE;
+    const bool vec = n % 4 == 0 && rs % 4 == 0 && aligned16(x) && aligned16(mean) && aligned16(stdv) &&
+                     (!o32 || aligned16(o32)) && (!o16 || (reinterpret_cast<uintptr_t>(o16) & 7) == 0);
+    const long work = (long)rows * n / (vec ? 4 : 1);
+    const int nb = blocks_for(work, TPB);
+    if (vec) hipLaunchKernelGGL((standardize_kernel<true>), dim3(nb), dim3(TPB), 0, as_stream(st), x, rs, mean, stdv, rows, n, o32, o16);
+    else hipLaunchKernelGGL((standardize_kernel<false>), dim3(nb), dim3(TPB), 0, as_stream(st), x, rs, mean, stdv, rows, n, o32, o16);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_destandardize_f32(const float* r, const float* mean, const float* stdv, int rows, int n, float* out, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    const long total = (long)rows * n;
+    hipLaunchKernelGGL(destandardize_kernel, dim3(blocks_for(total, TPB)), dim3(TPB), 0, as_stream(st), r, mean, stdv, total, n, out);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_relu_fwd_f32(const float* x, float* o, long n, void* st) {
+    if (n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), x, o, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_relu_bwd_f32(const float* x, const float* g, float* dx, long n, void* st) {
+    if (n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), x, g, dx, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_mask_positive_f32(const float* f, const float* g, float* dx, long n, void* st) {
+    if (n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(mask_positive_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), f, g, dx, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_jumprelu_fwd_f32(const float* x, const float* theta, float* o, int rows, int n, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    const long total = (long)rows * n;
+    hipLaunchKernelGGL(jumprelu_fwd_kernel, dim3(blocks_for(total, TPB)), dim3(TPB), 0, as_stream(st), x, theta, o, total, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_jumprelu_bwd_workspace_bytes(int rows, int n) { return (size_t)col_chunks(rows) * n * sizeof(float); }
+int clt_jumprelu_bwd_f32(const float* x, const float* theta, float bw, const float* g, float* dx, float* dtheta,
+                         int rows, int n, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    if (!ws || wsb < clt_jumprelu_bwd_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    const int ch = col_chunks(rows), rpc = (rows + ch - 1) / ch;
+    hipLaunchKernelGGL(jumprelu_bwd_kernel, dim3((n + TPB - 1) / TPB, ch), dim3(TPB), 0, as_stream(st), x, theta, bw, g,
+                       dx, (float*)ws, rows, n, rpc);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, as_stream(st), (const float*)ws, ch, n, dtheta, 0);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_column_sum_workspace_bytes(int rows, int n) { return (size_t)col_chunks(rows) * n * sizeof(float); }
+int clt_column_sum_f32(const float* x, int rows, int n, float* out, int accumulate, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    if (!ws || wsb < clt_column_sum_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    const int ch = col_chunks(rows), rpc = (rows + ch - 1) / ch;
+    hipLaunchKernelGGL(column_sum_kernel, dim3((n + TPB - 1) / TPB, ch), dim3(TPB), 0, as_stream(st), x, (float*)ws, rows, n, rpc);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, as_stream(st), (const float*)ws, ch, n, out, accumulate);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_reduce_workspace_bytes(long count) { return (size_t)blocks_for(count, TPB * 8, 2048) * sizeof(double); }
+int clt_mse_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,
+                float gs, float* g, float* ys_out, double* loss_sum, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0 || yrs < n) return CLT_ERR_SHAPE;
+    const long total = (long)rows * n;
+    if (!ws || wsb < clt_reduce_workspace_bytes(total)) return CLT_ERR_WORKSPACE;
+    const int nb = blocks_for(total, TPB * 8, 2048);
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(TPB), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g, ys_out, (double*)ws);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)ws, nb, 1, loss_sum);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_aux_mse_f32(const float* ar, const float* ys, const float* r, long total, float gs, float* ga, float* gm,
+                    double* aux_sum, void* ws, size_t wsb, void* st) {
+    if (total <= 0) return CLT_ERR_SHAPE;
+    if (!ws || wsb < clt_reduce_workspace_bytes(total)) return CLT_ERR_WORKSPACE;
+    const int nb = blocks_for(total, TPB * 8, 2048);
+    hipLaunchKernelGGL(aux_mse_kernel, dim3(nb), dim3(TPB), 0, as_stream(st), ar, ys, r, total, gs, ga, gm, (double*)ws);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)ws, nb, 1, aux_sum);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_row_sqnorm_f32(const float* W, int rows, int d, float* sq, int accumulate, void* st) {
+    if (rows <= 0 || d <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, as_stream(st), W, rows, d, sq, accumulate);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_rowscale_add_f32(const float* W, const float* dnorm, const float* sq, float* dW, int rows, int d, void* st) {
+    if (rows <= 0 || d <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, as_stream(st), W, dnorm, sq, dW, rows, d);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_jumprelu_loss_workspace_bytes(int rows, int n) {
+    const int ch = col_chunks(rows);
+    const size_t nblk = (size_t)((n + TPB - 1) / TPB) * ch;
+    return align_up((size_t)2 * ch * n * sizeof(float), 16) + nblk * 3 * sizeof(double);
+}
+int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* sq, const float* dfm, float bw,
+                              float lamB, float c, int use_tanh, float coefBL, float* dpre, float* dtheta,
+                              float* dnorm, double* sums, int rows, int n, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    if (!ws || wsb < clt_jumprelu_loss_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    if (dfm && (!dpre || !dtheta || !dnorm)) return CLT_ERR_SHAPE;
+    const int ch = col_chunks(rows), rpc = (rows + ch - 1) / ch, gx = (n + TPB - 1) / TPB;
+    float* pth = (float*)ws;
+    float* pdn = pth + (size_t)ch * n;
+    double* ps = (double*)((char*)ws + align_up((size_t)2 * ch * n * sizeof(float), 16));
+    hipLaunchKernelGGL(jumprelu_loss_kernel, dim3(gx, ch), dim3(TPB), 0, as_stream(st), x, theta, sq, dfm, bw, lamB, c,
+                       use_tanh, coefBL, dpre, pth, pdn, ps, rows, n, rpc);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * ch, 3, sums);
+    if (dfm) {
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pth, ch, n, dtheta, 0);
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pdn, ch, n, dnorm, 0);
+    }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_column_any_positive_f32(const float* f, int rows, int n, uint8_t* fired, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(column_any_positive_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, as_stream(st), f, rows, n, fired);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* la, long ttd, uint8_t* dead, int32_t* dead_count,
+                    void* st) {
+    if (n <= 0) return CLT_ERR_SHAPE;
+    if (hipMemsetAsync(dead_count, 0, sizeof(int32_t), as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(dead_update_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, as_stream(st), fired, n, tokens, la, ttd, dead, dead_count);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_mask_dead_f32(const float* x, const uint8_t* dead, float* o, int rows, int n, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    const long total = (long)rows * n;
+    hipLaunchKernelGGL(mask_dead_kernel, dim3(blocks_for(total, TPB)), dim3(TPB), 0, as_stream(st), x, dead, o, total, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_threshold_fwd_f32(const float* x, const float* thr, int per_layer, float* o, int B, int L, int F, void* st) {
+    if (B <= 0 || L <= 0 || F <= 0) return CLT_ERR_SHAPE;
+    const long total = (long)B * L * F;
+    hipLaunchKernelGGL(threshold_fwd_kernel, dim3(blocks_for(total, TPB)), dim3(TPB), 0, as_stream(st), x, thr, per_layer, o, total, L, F);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_cast_bf16(const float* in, uint16_t* out, long n, void* st) {
+    if (n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), in, out, n);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_cast_transpose_bf16(const float* in, long ldi, uint16_t* out, long ldo, int rows, int cols, int batch, long s_in,
+                            long s_out, void* st) {
+    if (rows <= 0 || cols <= 0 || batch <= 0 || ldi < cols || ldo < rows) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(TPB), 0, as_stream(st),
+                       in, ldi, out, ldo, rows, cols, s_in, s_out);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                 int adamw, int step, uint16_t* shadow, void* st) {
+    if (n <= 0 || step < 1) return CLT_ERR_SHAPE;
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)((double)lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
+    const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
+    const long n4 = vec ? n / 4 : 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
+                       lr, b1, b2, eps, wd, adamw, step_size, isb2, shadow);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+}  // extern "C"

@@ -1,0 +1,394 @@
+"""Tensor-level wrappers over the C ABI (include/clt_hip.h).
+
+PyTorch is used here only as plumbing: device memory (caching allocator), the current HIP stream and
+tensor metadata.  Every arithmetic operation below is one or more calls into libclt_hip.so; there is no
+torch / CPU fallback — a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from ._lib import call, lib
+
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, contiguous=True):
+    if not t.is_cuda:
+        raise RuntimeError("crosslayer_transcoder_amd ops need CUDA (HIP) tensors; there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return t
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-device scratch buffer, grown on demand (stream-ordered reuse on the current stream)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _rows_view(x: torch.Tensor) -> Tuple[int, int, int]:
+    """x: [B, ...] with contiguous inner dims (e.g. batch[:, 0]) -> (rows, n, row_stride)."""
+    B = x.shape[0]
+    n = x[0].numel()
+    if not x[0].is_contiguous():
+        raise ValueError("inner dimensions must be contiguous")
+    return B, n, (x.stride(0) if B > 1 else n)
+
+
+# ----------------------------------------------------------------------------------------------- K1
+def column_stats(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(x, contiguous=False)
+    rows, n, rs = _rows_view(x)
+    mean = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    std = torch.empty_like(mean)
+    call("clt_column_stats_f32", x.data_ptr(), rs, rows, n, mean.data_ptr(), std.data_ptr(), _stream())
+    return mean, std
+
+
+def standardize(x, mean, std, want_f32=True, want_bf16=False):
+    _chk(x, contiguous=False); _chk(mean); _chk(std)
+    rows, n, rs = _rows_view(x)
+    o32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    o16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    call("clt_standardize_f32", x.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n,
+         o32.data_ptr() if want_f32 else None, o16.data_ptr() if want_bf16 else None, _stream())
+    return o32, o16
+
+
+def destandardize(r, mean, std):
+    _chk(r); _chk(mean); _chk(std)
+    out = torch.empty_like(r)
+    call("clt_destandardize_f32", r.data_ptr(), mean.data_ptr(), std.data_ptr(), r.shape[0], r[0].numel(),
+         out.data_ptr(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------- dense GEMMs
+def _gemm(fn, A, aoff, B, boff, Cm, coff, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0,
+          bias=None, bias_off=0, sBias=0, accumulate=False):
+    es = A.element_size()
+    call(fn, A.data_ptr() + aoff * es, B.data_ptr() + boff * es, Cm.data_ptr() + coff * 4, M, N, K, lda, ldb, ldc,
+         int(tA), int(tB), batch, sA, sB, sC, (bias.data_ptr() + bias_off * 4) if bias is not None else None, sBias,
+         int(accumulate), _stream())
+
+
+def _fn_for(t):
+    return "clt_gemm_bf16" if t.dtype == torch.bfloat16 else "clt_gemm_f32"
+
+
+def encoder_fwd(xs: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """pre[b,l,:] = xs[b,l,:] @ W[l] + b[l]   (clt.py:157-165).  xs/W fp32, or both bf16 (W as [L,d,F])."""
+    Bn, L, d = xs.shape
+    F = W.shape[2]
+    _chk(xs, xs.dtype); _chk(W, xs.dtype)
+    pre = torch.empty(Bn, L, F, dtype=torch.float32, device=xs.device)
+    _gemm(_fn_for(xs), xs, 0, W, 0, pre, 0, Bn, F, d, L * d, F, L * F, False, False, batch=L, sA=d, sB=d * F, sC=F,
+          bias=b, sBias=F)
+    return pre
+
+
+def encoder_fwd_wt(xs16: torch.Tensor, Wt16: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """bf16 fast form: Wt16 is the transposed shadow [L,F,d] so both operands are k-contiguous."""
+    Bn, L, d = xs16.shape
+    F = Wt16.shape[1]
+    pre = torch.empty(Bn, L, F, dtype=torch.float32, device=xs16.device)
+    _gemm("clt_gemm_bf16", xs16, 0, Wt16, 0, pre, 0, Bn, F, d, L * d, d, L * F, False, True, batch=L, sA=d, sB=d * F,
+          sC=F, bias=b, sBias=F)
+    return pre
+
+
+def encoder_wgrad(xs: torch.Tensor, dpre: torch.Tensor) -> torch.Tensor:
+    """dW[l] = xs[:,l]^T @ dpre[:,l]."""
+    Bn, L, d = xs.shape
+    F = dpre.shape[2]
+    _chk(xs, xs.dtype); _chk(dpre, xs.dtype)
+    dW = torch.empty(L, d, F, dtype=torch.float32, device=xs.device)
+    _gemm(_fn_for(xs), xs, 0, dpre, 0, dW, 0, d, F, Bn, L * d, L * F, F, True, False, batch=L, sA=d, sB=F, sC=d * F)
+    return dW
+
+
+def clt_decoder_fwd(feat: torch.Tensor, Ws: List[torch.Tensor], b: Optional[torch.Tensor]) -> torch.Tensor:
+    """recons[:,l] = feat[:, :l+1].flatten(1) @ W_l.flatten(0,1) + b[l]   (clt.py:334-343)."""
+    Bn, L, F = feat.shape
+    d = Ws[0].shape[2]
+    _chk(feat, feat.dtype)
+    r = torch.empty(Bn, L, d, dtype=torch.float32, device=feat.device)
+    for l in range(L):
+        _gemm(_fn_for(feat), feat, 0, _chk(Ws[l], feat.dtype), 0, r, l * d, Bn, d, (l + 1) * F, L * F, d, L * d,
+              False, False, bias=b, bias_off=l * d)
+    return r
+
+
+def clt_decoder_dgrad(g: torch.Tensor, Ws: List[torch.Tensor]) -> torch.Tensor:
+    """dfeat[:, :l+1] += g[:,l] @ W_l.flatten(0,1)^T, l = L-1 first (covers every column, no zero fill)."""
+    Bn, L, d = g.shape
+    F = Ws[0].shape[1]
+    _chk(g, g.dtype)
+    df = torch.empty(Bn, L, F, dtype=torch.float32, device=g.device)
+    for l in range(L - 1, -1, -1):
+        _gemm(_fn_for(g), g, l * d, _chk(Ws[l], g.dtype), 0, df, 0, Bn, (l + 1) * F, d, L * d, d, L * F, False, True,
+              accumulate=(l != L - 1))
+    return df
+
+
+def clt_decoder_wgrad(feat: torch.Tensor, g: torch.Tensor, l: int, out: Optional[torch.Tensor] = None,
+                      accumulate=False) -> torch.Tensor:
+    """dW_l = feat[:, :l+1].flatten(1)^T @ g[:,l]   -> [(l+1), F, d]."""
+    Bn, L, F = feat.shape
+    d = g.shape[2]
+    if out is None:
+        out = torch.empty(l + 1, F, d, dtype=torch.float32, device=feat.device)
+    _gemm(_fn_for(feat), feat, 0, g, l * d, out, 0, (l + 1) * F, d, Bn, L * F, L * d, d, True, False,
+          accumulate=accumulate)
+    return out
+
+
+def plt_decoder_fwd(feat, W, b):
+    Bn, L, F = feat.shape
+    d = W.shape[2]
+    r = torch.empty(Bn, L, d, dtype=torch.float32, device=feat.device)
+    _gemm(_fn_for(feat), _chk(feat, feat.dtype), 0, _chk(W, feat.dtype), 0, r, 0, Bn, d, F, L * F, d, L * d, False,
+          False, batch=L, sA=F, sB=F * d, sC=d, bias=b, sBias=d)
+    return r
+
+
+def plt_decoder_dgrad(g, W):
+    Bn, L, d = g.shape
+    F = W.shape[1]
+    df = torch.empty(Bn, L, F, dtype=torch.float32, device=g.device)
+    _gemm(_fn_for(g), _chk(g, g.dtype), 0, _chk(W, g.dtype), 0, df, 0, Bn, F, d, L * d, d, L * F, False, True, batch=L,
+          sA=d, sB=F * d, sC=F)
+    return df
+
+
+def plt_decoder_wgrad(feat, g, out=None, accumulate=False):
+    Bn, L, F = feat.shape
+    d = g.shape[2]
+    if out is None:
+        out = torch.empty(L, F, d, dtype=torch.float32, device=feat.device)
+    _gemm(_fn_for(feat), feat, 0, g, 0, out, 0, F, d, Bn, L * F, L * d, d, True, False, batch=L, sA=F, sB=d, sC=F * d,
+          accumulate=accumulate)
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _chk(x)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("clt_cast_bf16", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
+    """[batch, rows, cols] fp32 -> [batch, cols, rows] bf16."""
+    _chk(x)
+    nb, rows, cols = x.shape
+    out = torch.empty(nb, cols, rows, dtype=torch.bfloat16, device=x.device)
+    call("clt_cast_transpose_bf16", x.data_ptr(), cols, out.data_ptr(), rows, rows, cols, nb, rows * cols, rows * cols,
+         _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- K3
+def relu_fwd(x):
+    out = torch.empty_like(_chk(x))
+    call("clt_relu_fwd_f32", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def relu_bwd(x, g):
+    dx = torch.empty_like(_chk(x))
+    call("clt_relu_bwd_f32", x.data_ptr(), _chk(g).data_ptr(), dx.data_ptr(), x.numel(), _stream())
+    return dx
+
+
+def jumprelu_fwd(x, theta):
+    _chk(x); _chk(theta)
+    rows, n = x.shape[0], x[0].numel()
+    assert theta.numel() == n
+    out = torch.empty_like(x)
+    call("clt_jumprelu_fwd_f32", x.data_ptr(), theta.data_ptr(), out.data_ptr(), rows, n, _stream())
+    return out
+
+
+def jumprelu_bwd(x, theta, bandwidth: float, g):
+    _chk(x); _chk(theta); _chk(g)
+    rows, n = x.shape[0], x[0].numel()
+    dx = torch.empty_like(x)
+    dth = torch.empty_like(theta)
+    nb = lib.clt_jumprelu_bwd_workspace_bytes(rows, n)
+    ws = workspace(nb, x.device)
+    call("clt_jumprelu_bwd_f32", x.data_ptr(), theta.data_ptr(), float(bandwidth), g.data_ptr(), dx.data_ptr(),
+         dth.data_ptr(), rows, n, ws.data_ptr(), ws.numel(), _stream())
+    return dx, dth
+
+
+# ----------------------------------------------------------------------------------------------- K4
+def topk_rows(x, k: int, want_compact=False):
+    _chk(x)
+    Bn, L, F = x.shape
+    feat = torch.empty_like(x)
+    idx = val = None
+    if want_compact:
+        idx = torch.empty(Bn * L, max(k, 1), dtype=torch.int32, device=x.device)
+        val = torch.empty(Bn * L, max(k, 1), dtype=torch.float32, device=x.device)
+    call("clt_topk_rows_f32", x.data_ptr(), feat.data_ptr(), Bn * L, F, k, idx.data_ptr() if want_compact else None,
+         val.data_ptr() if want_compact else None, _stream())
+    return (feat, idx, val) if want_compact else feat
+
+
+def topk_segmented(x, k: int, per_layer: bool, threshold: Optional[torch.Tensor], e: float):
+    """BatchTopK (per_layer=False) / PerLayerBatchTopK (True); `threshold` is updated in place."""
+    _chk(x)
+    Bn, L, F = x.shape
+    feat = torch.empty_like(x)
+    nb = lib.clt_topk_segmented_workspace_bytes(Bn, L, F, int(per_layer))
+    ws = workspace(nb, x.device)
+    if threshold is not None:
+        _chk(threshold)
+    call("clt_topk_segmented_f32", x.data_ptr(), feat.data_ptr(), Bn, L, F, k, int(per_layer),
+         threshold.data_ptr() if threshold is not None else None, float(e or 0.0), ws.data_ptr(), ws.numel(), _stream())
+    return feat
+
+
+def mask_positive(feat, g):
+    dx = torch.empty_like(_chk(feat))
+    call("clt_mask_positive_f32", feat.data_ptr(), _chk(g).data_ptr(), dx.data_ptr(), feat.numel(), _stream())
+    return dx
+
+
+def threshold_fwd(x, threshold, per_layer: bool, L: int):
+    """Inference path; x: [..., F] of one layer or [B, L, F]."""
+    _chk(x); _chk(threshold)
+    out = torch.empty_like(x)
+    F = x.shape[-1]
+    rows = x.numel() // F
+    if per_layer:
+        call("clt_threshold_fwd_f32", x.data_ptr(), threshold.data_ptr(), 1, out.data_ptr(), rows // L, L, F, _stream())
+    else:
+        call("clt_threshold_fwd_f32", x.data_ptr(), threshold.data_ptr(), 0, out.data_ptr(), rows, 1, F, _stream())
+    return out
+
+
+def mask_dead(x, dead_u8):
+    _chk(x); _chk(dead_u8, torch.uint8)
+    out = torch.empty_like(x)
+    call("clt_mask_dead_f32", x.data_ptr(), dead_u8.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------- K8 - K12
+def mse(r, y, mean, std, want_grad=True, want_ys=False):
+    """Returns (loss_sum fp64 [1], g or None, ys or None); g = 2/(B*L*d) * (r - ys)."""
+    _chk(r); _chk(y, contiguous=False); _chk(mean); _chk(std)
+    rows, n, rs = _rows_view(y)
+    g = torch.empty_like(r) if want_grad else None
+    ys = torch.empty_like(r) if want_ys else None
+    loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
+    nb = lib.clt_reduce_workspace_bytes(rows * n)
+    ws = workspace(nb, r.device)
+    call("clt_mse_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (rows * n),
+         g.data_ptr() if want_grad else None, ys.data_ptr() if want_ys else None, loss_sum.data_ptr(), ws.data_ptr(),
+         ws.numel(), _stream())
+    return loss_sum, g, ys
+
+
+def aux_mse(aux_r, ys, r, g_main, scale: float):
+    """g_aux = scale*2/N * e (finite only); g_main += g_aux in place.  Returns (aux_sum fp64 [1], g_aux)."""
+    for t in (aux_r, ys, r, g_main):
+        _chk(t)
+    n = r.numel()
+    g_aux = torch.empty_like(r)
+    s = torch.empty(1, dtype=torch.float64, device=r.device)
+    nb = lib.clt_reduce_workspace_bytes(n)
+    ws = workspace(nb, r.device)
+    call("clt_aux_mse_f32", aux_r.data_ptr(), ys.data_ptr(), r.data_ptr(), n, scale * 2.0 / n, g_aux.data_ptr(),
+         g_main.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return s, g_aux
+
+
+def column_sum(x, out=None, accumulate=False):
+    _chk(x)
+    rows, n = x.shape[0], x[0].numel()
+    if out is None:
+        out = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+    nb = lib.clt_column_sum_workspace_bytes(rows, n)
+    ws = workspace(nb, x.device)
+    call("clt_column_sum_f32", x.data_ptr(), rows, n, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(),
+         _stream())
+    return out
+
+
+def row_sqnorm(W, sq, sq_off=0, accumulate=True):
+    """sq[sq_off + row] (+)= sum_d W[row]^2 for the rows of W flattened to [rows, d]."""
+    _chk(W); _chk(sq)
+    d = W.shape[-1]
+    rows = W.numel() // d
+    call("clt_row_sqnorm_f32", W.data_ptr(), rows, d, sq.data_ptr() + 4 * sq_off, int(accumulate), _stream())
+
+
+def jumprelu_loss_bwd(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_tanh, coef_over_BL):
+    """Fused JumpReLU-module loss terms + backward through the sparsifier (clt_lightning.py:438-468).
+    Returns (sums fp64 [3] = [sum t, sum relu(-pre), sum w], dpre, dtheta, dnorm)."""
+    _chk(pre); _chk(theta); _chk(sq)
+    rows, n = pre.shape[0], pre[0].numel()
+    sums = torch.empty(3, dtype=torch.float64, device=pre.device)
+    have = dfeat_main is not None
+    dpre = torch.empty_like(pre) if have else None
+    dth = torch.empty_like(theta) if have else None
+    dn = torch.empty(n, dtype=torch.float32, device=pre.device) if have else None
+    nb = lib.clt_jumprelu_loss_workspace_bytes(rows, n)
+    ws = workspace(nb, pre.device)
+    call("clt_jumprelu_loss_bwd_f32", pre.data_ptr(), theta.data_ptr(), sq.data_ptr(),
+         _chk(dfeat_main).data_ptr() if have else None, float(bandwidth), float(lam_over_B), float(c), int(use_tanh),
+         float(coef_over_BL), dpre.data_ptr() if have else None, dth.data_ptr() if have else None,
+         dn.data_ptr() if have else None, sums.data_ptr(), rows, n, ws.data_ptr(), ws.numel(), _stream())
+    return sums, dpre, dth, dn
+
+
+def rowscale_add(W, dnorm, sq, dW, off=0):
+    """dW[row] += dnorm[off+row]/sqrt(sq[off+row]) * W[row]."""
+    d = W.shape[-1]
+    rows = W.numel() // d
+    call("clt_rowscale_add_f32", _chk(W).data_ptr(), _chk(dnorm).data_ptr() + 4 * off, _chk(sq).data_ptr() + 4 * off,
+         _chk(dW).data_ptr(), rows, d, _stream())
+
+
+def column_any_positive(feat):
+    _chk(feat)
+    rows, n = feat.shape[0], feat[0].numel()
+    fired = torch.empty(feat.shape[1:], dtype=torch.uint8, device=feat.device)
+    call("clt_column_any_positive_f32", feat.data_ptr(), rows, n, fired.data_ptr(), _stream())
+    return fired
+
+
+def dead_update(fired, tokens: int, last_active, tokens_till_dead: int):
+    """In-place last_active update (clt_lightning.py:282-288); returns (dead uint8 [L,F], dead_count int32 [1])."""
+    _chk(fired, torch.uint8); _chk(last_active, torch.int64)
+    dead = torch.empty_like(fired)
+    cnt = torch.empty(1, dtype=torch.int32, device=fired.device)
+    call("clt_dead_update", fired.data_ptr(), fired.numel(), int(tokens), last_active.data_ptr(), int(tokens_till_dead),
+         dead.data_ptr(), cnt.data_ptr(), _stream())
+    return dead, cnt
+
+
+# ---------------------------------------------------------------------------------------------- K13
+def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False,
+         bf16_shadow=None):
+    for t in (p, g, m, v):
+        _chk(t)
+    call("clt_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(weight_decay), int(adamw), int(step),
+         bf16_shadow.data_ptr() if bf16_shadow is not None else None, _stream())

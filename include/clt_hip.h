@@ -1,0 +1,169 @@
+/*
+ * clt_hip.h — C ABI of libclt_hip.so: the MI355X (gfx950) kernels of the crosslayer-transcoder
+ * training step.  This is the drop-in boundary: plain device pointers, sizes and a hipStream_t
+ * (passed as void*); no torch types.  The reference has no FFI of its own on this path — it
+ * reaches stock ATen kernels through einops/torch — so each entry point cites the reference
+ * Python op sequence (file:line, relative to the reference repo root) that it replaces.
+ *
+ * Rules for every entry point
+ *   - stream-ordered, asynchronous, no host synchronisation, no allocation (hipMalloc/hipFree):
+ *     scratch comes in through `workspace` (size from the matching *_workspace_bytes query);
+ *   - returns CLT_OK (0) or a negative CLT_ERR_* code; nothing is launched on error;
+ *   - all tensors are dense row-major unless a leading dimension / row stride is given (in ELEMENTS);
+ *   - float = IEEE fp32, bf16 = the upper 16 bits of fp32 (round-to-nearest-even), carried as uint16_t.
+ */
+#ifndef CLT_HIP_H
+#define CLT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLT_OK 0
+#define CLT_ERR_SHAPE (-1)      /* non-positive / inconsistent dimension                           */
+#define CLT_ERR_K_GT_F (-2)     /* k > d_features: the host raises AssertionError (topk.py:56,80,113) */
+#define CLT_ERR_WORKSPACE (-3)  /* workspace NULL or too small                                      */
+#define CLT_ERR_ALIGN (-4)      /* pointer / stride alignment the kernel needs is not met           */
+#define CLT_ERR_LAUNCH (-5)     /* hipGetLastError() != hipSuccess after the launch                 */
+#define CLT_ERR_RANGE (-6)      /* element count exceeds the 32-bit index range of the kernel       */
+
+/* Library / build identification ("gfx950"), and the ABI version checked by the Python loader. */
+const char* clt_arch(void);
+int clt_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  standardizers — model/standardize.py:39-59, :80-108
+ * ------------------------------------------------------------------------------------------- */
+/* mean[n], std[n] (unbiased, clamped at 1e-8) over `rows` samples of x[r*row_stride + j]. */
+int clt_column_stats_f32(const float* x, long row_stride, int rows, int n, float* mean, float* std,
+                         void* stream);
+/* out[r,j] = (x[r*row_stride+j] - mean[j]) / std[j]; out_f32 and/or out_bf16 may be NULL. */
+int clt_standardize_f32(const float* x, long row_stride, const float* mean, const float* std, int rows,
+                        int n, float* out_f32, uint16_t* out_bf16, void* stream);
+/* out[r,j] = r_in[r,j]*std[j] + mean[j]  (standardize.py:96). */
+int clt_destandardize_f32(const float* r_in, const float* mean, const float* std, int rows, int n,
+                          float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2/K5/K6/K7  dense contractions — clt.py:157-165 (encoder einsum + bias), :334-343 (cross-layer
+ * decoder loop), :241-248 (per-layer decoder) and their autograd (bmm backward).
+ *
+ * C[b] (M x N, ldc) (+)= op(A[b]) (M x K) * op(B[b]) (K x N) + bias[b][N]
+ *   transA = 0: A stored [M][K] (lda >= K);   1: A stored [K][M] (lda >= M)
+ *   transB = 0: B stored [K][N] (ldb >= N);   1: B stored [N][K] (ldb >= K)
+ * `batch` problems at element strides sA/sB/sC/sBias.  bias may be NULL.  accumulate != 0: C += .
+ * f32: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the parity path (rtol 1e-5 vs the fp32 reference).
+ * bf16: bf16 operands (uint16_t), fp32 accumulate and fp32 C  (v_mfma_f32_32x32x16_bf16).
+ * ------------------------------------------------------------------------------------------- */
+int clt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
+                 long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
+                 const float* bias, long sBias, int accumulate, void* stream);
+int clt_gemm_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb,
+                  long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
+                  const float* bias, long sBias, int accumulate, void* stream);
+/* fp32 -> bf16 (RNE) copy, optionally transposing a [rows][cols] matrix (ld_in) to [cols][rows] (ld_out). */
+int clt_cast_bf16(const float* in, uint16_t* out, long n, void* stream);
+int clt_cast_transpose_bf16(const float* in, long ld_in, uint16_t* out, long ld_out, int rows, int cols,
+                            int batch, long s_in, long s_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  ReLU / JumpReLU — model/jumprelu.py:17-22, :31-48
+ * x, out, g: [rows][n] (n = L*F); theta: [n]
+ * ------------------------------------------------------------------------------------------- */
+int clt_relu_fwd_f32(const float* x, float* out, long count, void* stream);
+int clt_relu_bwd_f32(const float* x, const float* g, float* dx, long count, void* stream);
+int clt_jumprelu_fwd_f32(const float* x, const float* theta, float* out, int rows, int n, void* stream);
+/* dx = g where x >= 0 else 0;  dtheta[j] = sum_r -(theta/bw)*rect((x-theta)/bw)*g.  Deterministic
+ * two-stage column reduction through `workspace`. */
+size_t clt_jumprelu_bwd_workspace_bytes(int rows, int n);
+int clt_jumprelu_bwd_f32(const float* x, const float* theta, float bandwidth, const float* g, float* dx,
+                         float* dtheta, int rows, int n, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  TopK / BatchTopK / PerLayerBatchTopK selection — model/topk.py:53-63, :76-96, :109-133
+ * Exact radix select on order-preserving fp32 keys; ties at the k-th value go to the LOWER index.
+ * x: [B][L][F] contiguous fp32.  feat_out (dense, same shape) = relu(x) at selected positions, else 0.
+ * ------------------------------------------------------------------------------------------- */
+/* mode 0: k of F per (b,l) row.  idx_out/val_out: optional [B*L][k] compact copies (int32 feature id,
+ * relu'd value; unused slots of a row hold idx = -1, val = 0 — only when k-th value <= 0). */
+int clt_topk_rows_f32(const float* x, float* feat_out, int rows, int F, int k, int32_t* idx_out,
+                      float* val_out, void* stream);
+/* mode 1 (per_layer = 0): global top k*B*L of B*L*F.  mode 2 (per_layer = 1): per layer l, top k*B of
+ * the B*F entries x[:, l, :].  threshold[S] (S = 1 or L) is updated in place:
+ * thr <- (1-e)*thr + e*max(kth_value, 0); pass threshold = NULL to skip.  k == 0 -> zeros, no update. */
+size_t clt_topk_segmented_workspace_bytes(int B, int L, int F, int per_layer);
+int clt_topk_segmented_f32(const float* x, float* feat_out, int B, int L, int F, int k, int per_layer,
+                           float* threshold, float ema_e, void* workspace, size_t ws_bytes, void* stream);
+/* backward of scatter(relu(gather)): dx = g * [feat > 0]. */
+int clt_mask_positive_f32(const float* feat, const float* g, float* dx, long count, void* stream);
+/* inference path (topk.py:71-74, 104-107): out = x > max(thr[seg],0) ? x : 0, seg = 0 or layer. */
+int clt_threshold_fwd_f32(const float* x, const float* threshold, int per_layer, float* out, int B, int L,
+                          int F, void* stream);
+/* where(dead[l,f], x, -inf)  (clt_lightning.py:544-545); dead: uint8 [n]. */
+int clt_mask_dead_f32(const float* x, const uint8_t* dead, float* out, int rows, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  reconstruction MSE + its gradient — clt_lightning.py:303-304, 434, 536
+ * diff = r - (y - mean)/std ;  loss_sum[0] = sum diff^2 ;  g = grad_scale * diff  (grad_scale = 2/(B*L*d)).
+ * y rows are strided (batch[:,1]).  g may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+size_t clt_reduce_workspace_bytes(long count);
+int clt_mse_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std,
+                int rows, int n, float grad_scale, float* g, float* ys_out, double* loss_sum,
+                void* workspace, size_t ws_bytes, void* stream);
+/* TopK aux loss — clt_lightning.py:548-553: e = aux_r - (ys - r); aux_sum = sum nan_to_num(e^2);
+ * g_aux = grad_scale*e*[isfinite(e^2)];  g_main += g_aux (recons_err is not detached). */
+int clt_aux_mse_f32(const float* aux_r, const float* ys, const float* r, long count, float grad_scale,
+                    float* g_aux, float* g_main, double* aux_sum, void* workspace, size_t ws_bytes,
+                    void* stream);
+/* column sums: out[j] (+)= sum_r x[r][j]  (bias gradients). */
+size_t clt_column_sum_workspace_bytes(int rows, int n);
+int clt_column_sum_f32(const float* x, int rows, int n, float* out, int accumulate, void* workspace,
+                       size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9/K10  JumpReLU-module sparsity + pre-activation losses — clt_lightning.py:438-468
+ * ------------------------------------------------------------------------------------------- */
+/* sq[row] (+)= sum_d W[row][d]^2   (dec_norms accumulation, one call per W_l, rows = (l+1)*F). */
+int clt_row_sqnorm_f32(const float* W, int rows, int d, float* sq, int accumulate, void* stream);
+/* Fused elementwise pass of the JumpReLU training step, x = pre [rows][n], n = L*F:
+ *   f = jumprelu(x, theta); w = f*sqrt(sq[j])*c; t = tanh(w) | w
+ *   sums[0] = sum t ; sums[1] = sum relu(-x) ; sums[2] = sum w   (loss terms, as raw sums; overwritten)
+ *   dfeat   = dfeat_main + lam_over_B * dt * c * norm           (dt = 1-t^2 | 1)
+ *   dpre    = (x < 0 ? 0 : dfeat) - coef_over_BL*[x < 0]
+ *   dtheta[j] = sum_r -(theta/bw)*rect((x-theta)/bw)*dfeat
+ *   dnorm[j]  = sum_r lam_over_B * dt * c * f
+ * dfeat_main may be NULL (loss terms only; dpre/dtheta/dnorm then skipped). */
+size_t clt_jumprelu_loss_workspace_bytes(int rows, int n);
+int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* sq, const float* dfeat_main,
+                              float bandwidth, float lam_over_B, float c, int use_tanh, float coef_over_BL,
+                              float* dpre, float* dtheta, float* dnorm, double* sums, int rows, int n,
+                              void* workspace, size_t ws_bytes, void* stream);
+/* dW[row][:] += (dnorm[row]/sqrt(sq[row])) * W[row][:]   (gradient through dec_norms). */
+int clt_rowscale_add_f32(const float* W, const float* dnorm, const float* sq, float* dW, int rows, int d,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K12  dead-feature bookkeeping — clt_lightning.py:282-288
+ * fired[j] = any_r feat[r][j] > 0   (features.sum(0) > 0 on non-negative features)
+ * last_active[j] = (fired[j] ? 0 : last_active[j]) + tokens ; dead[j] = last_active[j] > tokens_till_dead ;
+ * dead_count[0] = sum_j dead[j]   (logged as metrics/dead_features = dead_count / n).
+ * ------------------------------------------------------------------------------------------- */
+int clt_column_any_positive_f32(const float* feat, int rows, int n, uint8_t* fired, void* stream);
+int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* last_active, long tokens_till_dead,
+                    uint8_t* dead, int32_t* dead_count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K13  fused Adam / AdamW — clt_lightning.py:339-352 (torch.optim semantics, eps outside sqrt)
+ * step counts from 1.  bf16_shadow (optional) receives the updated weights rounded to bf16.
+ * ------------------------------------------------------------------------------------------- */
+int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int adamw, int step, uint16_t* bf16_shadow,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLT_HIP_H */

@@ -1,0 +1,277 @@
+"""GPU parity of each C-ABI entry point (through crosslayer_transcoder_amd.ops -> libclt_hip.so) against the
+CPU oracle on the same seeded inputs.  fp32 tolerance: rtol 1e-5 (+ atol scaled to the output magnitude for
+sums); selection: bit-exact."""
+import pytest
+import torch
+
+from oracle import clt_oracle as O
+from tests.golden_cases import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from crosslayer_transcoder_amd import ops as _ops
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def tol(ref, rtol=1e-5):
+    return dict(rtol=rtol, atol=rtol * float(ref.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("B,L,d", [(16, 2, 110), (7, 3, 13), (300, 4, 64)])
+def test_standardizer(ops, B, L, d):
+    batch = _rand(B, 2, L, d, seed=1) * 2 + 0.5
+    ref = O.standardizer_init(batch)
+    bd = batch.to(DEV)
+    m, s = ops.column_stats(bd[:, 0])
+    assert_close(m, ref["in_mean"], 1e-5, 1e-6, "mean"); assert_close(s, ref["in_std"], 1e-5, 1e-7, "std")
+    m1, s1 = ops.column_stats(bd[:, 1])
+    assert_close(m1, ref["out_mean"], 1e-5, 1e-6); assert_close(s1, ref["out_std"], 1e-5, 1e-7)
+    xs32, xs16 = ops.standardize(bd[:, 0], ref["in_mean"].to(DEV), ref["in_std"].to(DEV), True, True)
+    want = O.standardize(batch[:, 0], ref["in_mean"], ref["in_std"])
+    assert torch.equal(xs32.cpu(), want)                          # same IEEE sub + div
+    assert torch.equal(xs16.cpu(), want.to(torch.bfloat16))
+    r = _rand(B, L, d, seed=2)
+    assert_close(ops.destandardize(r.to(DEV), m1, s1), O.destandardize(r, ref["out_mean"], ref["out_std"]), 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("B,L,d,F", [(16, 2, 110, 32), (5, 3, 7, 9), (130, 2, 96, 200), (64, 12, 768, 256)])
+def test_dense_contractions_f32(ops, B, L, d, F):
+    xs, W, b = _rand(B, L, d, seed=1), _rand(L, d, F, seed=2, scale=F ** -0.5), _rand(L, F, seed=3, scale=0.1)
+    pre = ops.encoder_fwd(xs.to(DEV), W.to(DEV), b.to(DEV))
+    ref = O.encoder_fwd(xs.double(), W.double(), b.double())
+    assert_close(pre, ref, **tol(ref), what="encoder fwd")
+    dpre = _rand(B, L, F, seed=4)
+    dW = ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV))
+    rW, _ = O.encoder_bwd(xs.double(), dpre.double())
+    assert_close(dW, rW, **tol(rW), what="encoder wgrad")
+    feat = torch.relu(_rand(B, L, F, seed=5))
+    Ws = [_rand(l + 1, F, d, seed=10 + l, scale=0.05) for l in range(L)]
+    bd = _rand(L, d, seed=6, scale=0.1)
+    r = ops.clt_decoder_fwd(feat.to(DEV), [w.to(DEV) for w in Ws], bd.to(DEV))
+    rr = O.crosslayer_decoder_fwd(feat.double(), [w.double() for w in Ws], bd.double())
+    assert_close(r, rr, **tol(rr), what="clt decoder fwd")
+    g = _rand(B, L, d, seed=7)
+    rdf, rdWs, _ = O.crosslayer_decoder_bwd(feat.double(), [w.double() for w in Ws], g.double())
+    df = ops.clt_decoder_dgrad(g.to(DEV), [w.to(DEV) for w in Ws])
+    assert_close(df, rdf, **tol(rdf), what="clt decoder dgrad")
+    for l in range(L):
+        assert_close(ops.clt_decoder_wgrad(feat.to(DEV), g.to(DEV), l), rdWs[l], **tol(rdWs[l]), what=f"wgrad {l}")
+    Wp = _rand(L, F, d, seed=8, scale=0.05)
+    assert_close(ops.plt_decoder_fwd(feat.to(DEV), Wp.to(DEV), bd.to(DEV)),
+                 O.plt_decoder_fwd(feat.double(), Wp.double(), bd.double()), **tol(rr), what="plt fwd")
+    pdf, pdW, _ = O.plt_decoder_bwd(feat.double(), Wp.double(), g.double())
+    assert_close(ops.plt_decoder_dgrad(g.to(DEV), Wp.to(DEV)), pdf, **tol(pdf), what="plt dgrad")
+    assert_close(ops.plt_decoder_wgrad(feat.to(DEV), g.to(DEV)), pdW, **tol(pdW), what="plt wgrad")
+    assert_close(ops.column_sum(g.to(DEV)), g.double().sum(0), **tol(g.double().sum(0)), what="colsum")
+
+
+def test_gemm_layout_asymmetric(ops):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide §3)."""
+    n = 96
+    Bm = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    eye = torch.eye(n)
+    out = ops.plt_decoder_fwd(eye.reshape(n, 1, n).to(DEV), Bm.reshape(1, n, n).to(DEV), None)
+    assert torch.equal(out.cpu().reshape(n, n), Bm)
+
+
+@pytest.mark.parametrize("B,L,d,F", [(64, 2, 128, 256), (130, 3, 72, 200)])
+def test_dense_contractions_bf16(ops, B, L, d, F):
+    """bf16 operands, fp32 accumulate: compared with the fp64 product of the SAME bf16-rounded operands."""
+    bf = torch.bfloat16
+    xs, W = _rand(B, L, d, seed=1).to(bf), _rand(L, d, F, seed=2, scale=F ** -0.5).to(bf)
+    b = _rand(L, F, seed=3, scale=0.1)
+    ref = O.encoder_fwd(xs.double(), W.double(), b.double())
+    assert_close(ops.encoder_fwd(xs.to(DEV), W.to(DEV), b.to(DEV)), ref, **tol(ref, 2e-6), what="enc bf16")
+    Wt = W.transpose(1, 2).contiguous()
+    assert_close(ops.encoder_fwd_wt(xs.to(DEV), Wt.to(DEV), b.to(DEV)), ref, **tol(ref, 2e-6), what="enc bf16 NT")
+    dpre = _rand(B, L, F, seed=4).to(bf)
+    rW, _ = O.encoder_bwd(xs.double(), dpre.double())
+    assert_close(ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV)), rW, **tol(rW, 2e-6), what="enc wgrad bf16")
+    feat = torch.relu(_rand(B, L, F, seed=5)).to(bf)
+    Ws = [_rand(l + 1, F, d, seed=10 + l, scale=0.05).to(bf) for l in range(L)]
+    g = _rand(B, L, d, seed=7).to(bf)
+    rr = O.crosslayer_decoder_fwd(feat.double(), [w.double() for w in Ws], torch.zeros(L, d).double())
+    assert_close(ops.clt_decoder_fwd(feat.to(DEV), [w.to(DEV) for w in Ws], None), rr, **tol(rr, 2e-6), what="dec bf16")
+    rdf, rdWs, _ = O.crosslayer_decoder_bwd(feat.double(), [w.double() for w in Ws], g.double())
+    assert_close(ops.clt_decoder_dgrad(g.to(DEV), [w.to(DEV) for w in Ws]), rdf, **tol(rdf, 2e-6), what="dgrad bf16")
+    assert_close(ops.clt_decoder_wgrad(feat.to(DEV), g.to(DEV), L - 1), rdWs[L - 1], **tol(rdWs[L - 1], 2e-6))
+    x32 = _rand(3, 70, 130, seed=9)
+    assert torch.equal(ops.cast_transpose_bf16(x32.to(DEV)).cpu(), x32.to(bf).transpose(1, 2).contiguous())
+    assert torch.equal(ops.cast_bf16(x32.to(DEV)).cpu(), x32.to(bf))
+
+
+def test_relu_jumprelu(ops, golden):
+    c = golden("jumprelu_fn")
+    x, th, go = c["x"].to(DEV), c["theta"].to(DEV), c["grad_out"].to(DEV)
+    assert torch.equal(ops.jumprelu_fwd(x, th).cpu(), c["out"])
+    dx, dth = ops.jumprelu_bwd(x, th, float(c["bandwidth"]), go)
+    assert torch.equal(dx.cpu(), c["dx"])
+    assert_close(dth, c["dtheta"], 1e-5, 1e-6, "dtheta")
+    xx = _rand(33, 5, 17, seed=3)
+    gg = _rand(33, 5, 17, seed=4)
+    assert torch.equal(ops.relu_fwd(xx.to(DEV)).cpu(), O.relu_fwd(xx))
+    assert torch.equal(ops.relu_bwd(xx.to(DEV), gg.to(DEV)).cpu(), O.relu_bwd(xx, gg))
+    # larger, with many points inside the rectangle window
+    x = _rand(513, 3, 300, seed=5, scale=0.1); th = torch.full((1, 3, 300), 0.05) + _rand(1, 3, 300, seed=6, scale=0.01)
+    go = _rand(513, 3, 300, seed=7)
+    dxr, dthr = O.jumprelu_bwd(x, th, 0.04, go)
+    dx, dth = ops.jumprelu_bwd(x.to(DEV), th.to(DEV), 0.04, go.to(DEV))
+    assert torch.equal(dx.cpu(), dxr)
+    assert_close(dth, dthr.double(), 1e-4, 1e-4 * float(dthr.abs().max()), "dtheta big")
+
+
+def test_selection_golden(ops, golden):
+    sel = golden("selection")
+    for key, c in sel.items():
+        x, k = c["x"].to(DEV), int(c["k"])
+        L = x.shape[1]
+        assert torch.equal(ops.topk_rows(x, k).cpu(), c["topk"]), key
+        thr = torch.zeros(1, device=DEV)
+        assert torch.equal(ops.topk_segmented(x, k, False, thr, 0.1).cpu(), c["batchtopk"]), key
+        assert_close(thr, c["batchtopk_threshold"], 1e-6, 0)
+        thr = torch.zeros(L, device=DEV)
+        assert torch.equal(ops.topk_segmented(x, k, True, thr, 0.1).cpu(), c["perlayerbatchtopk"]), key
+        assert_close(thr, c["perlayerbatchtopk_threshold"], 1e-6, 0)
+
+
+@pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (1, 1, 5, 3), (2, 8, 10, 3), (1, 12, 768, 3), (10, 1, 3, 3),
+                                     (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8)])
+def test_selection_vs_oracle(ops, B, L, F, k):
+    x = _rand(B, L, F, seed=B + F)
+    xd = x.to(DEV)
+    f, idx, val = ops.topk_rows(xd, k, want_compact=True)
+    ref, ridx = O.per_layer_topk_fwd(x, k)
+    assert torch.equal(f.cpu(), ref)
+    ridx_sorted = ridx.sort(-1).values.reshape(B * L, k)
+    rval = torch.gather(ref.reshape(B * L, F), 1, ridx_sorted)
+    pos = rval > 0
+    got_idx, got_val = idx.cpu(), val.cpu()
+    for r in range(0, B * L, max(1, B * L // 50)):     # positive entries, ascending feature id, then (-1, 0) padding
+        n = int(pos[r].sum())
+        assert torch.equal(got_idx[r, :n].long(), ridx_sorted[r][pos[r]]) and torch.equal(got_val[r, :n], rval[r][pos[r]])
+        assert (got_idx[r, n:] == -1).all() and (got_val[r, n:] == 0).all()
+    thr = torch.full((1,), 0.25, device=DEV)
+    fb = ops.topk_segmented(xd, k, False, thr, 0.1)
+    rb, _, mk = O.batch_topk_fwd(x, k)
+    assert torch.equal(fb.cpu(), rb)
+    assert_close(thr, O.threshold_ema(torch.full((1,), 0.25), mk, 0.1), 1e-6, 1e-8)
+    thr = torch.zeros(L, device=DEV)
+    fl = ops.topk_segmented(xd, k, True, thr, 0.05)
+    rl, _, mk = O.per_layer_batch_topk_fwd(x, k)
+    assert torch.equal(fl.cpu(), rl)
+    assert_close(thr, O.threshold_ema(torch.zeros(L), mk, 0.05), 1e-6, 1e-8)
+
+
+def test_selection_edges_and_ties(ops):
+    x = (torch.rand(3, 4, 5) + 0.1).to(DEV)                        # reference tests/test_topk.py:137-180
+    for fn in (lambda k: ops.topk_rows(x, k), lambda k: ops.topk_segmented(x, k, False, None, 0.0),
+               lambda k: ops.topk_segmented(x, k, True, None, 0.0)):
+        assert torch.equal(fn(0), torch.zeros_like(x))
+        assert torch.equal(fn(5), x)
+        with pytest.raises(AssertionError):
+            fn(6)
+    # heavy positive ties: canonical rule = larger value, then lower index — bit-exact with the oracle
+    g = torch.Generator().manual_seed(0)
+    t = torch.randint(0, 6, (40, 3, 512), generator=g).float() - 1.0
+    td = t.to(DEV)
+    for k in (1, 7, 100):
+        assert torch.equal(ops.topk_rows(td, k).cpu(), O.per_layer_topk_fwd(t, k)[0])
+        assert torch.equal(ops.topk_segmented(td, k, False, None, 0.0).cpu(), O.batch_topk_fwd(t, k)[0])
+        assert torch.equal(ops.topk_segmented(td, k, True, None, 0.0).cpu(), O.per_layer_batch_topk_fwd(t, k)[0])
+    # aux path: -inf masked rows with fewer finite entries than k
+    m = _rand(8, 3, 64, seed=2)
+    dead = (torch.rand(3, 64, generator=g) < 0.1)
+    md = ops.mask_dead(m.to(DEV), dead.to(torch.uint8).to(DEV))
+    mref = torch.where(dead.expand_as(m), m, torch.full_like(m, -float("inf")))
+    assert torch.equal(md.cpu(), mref)
+    assert torch.equal(ops.topk_rows(md, 20).cpu(), O.per_layer_topk_fwd(mref, 20)[0])
+    # known answers (reference tests/test_topk.py:77-113)
+    ka = torch.tensor([[[1, 2, 3, 4, 5], [6, 7, 8, 9, 10]]], dtype=torch.float32, device=DEV)
+    assert torch.equal(ops.topk_rows(ka, 3).cpu(), torch.tensor([[[0., 0, 3, 4, 5], [0, 0, 8, 9, 10]]]))
+    two = torch.tensor([[[1, 2, 3, 4, 5], [6, 7, 8, 9, 10]], [[11, 12, 13, 14, 15], [16, 17, 18, 19, 20]]],
+                       dtype=torch.float32, device=DEV)
+    fb = ops.topk_segmented(two, 3, False, None, 0.0).cpu()
+    assert (fb != 0).sum() == 12 and fb[1, 1, 4] == 20 and fb[1, 1, 3] == 19
+    fl = ops.topk_segmented(two, 3, True, None, 0.0).cpu()
+    assert (fl[:, 0] != 0).sum() == 6 and (fl[:, 1] != 0).sum() == 6
+    # inference thresholds (topk.py:71-74, 104-107)
+    thr = torch.tensor([0.3, -1.0, 0.7], device=DEV)
+    xi = _rand(5, 3, 33, seed=9)
+    out = ops.threshold_fwd(xi.to(DEV), thr, True, 3).cpu()
+    for l in range(3):
+        assert torch.equal(out[:, l], O.topk_inference(xi[:, l], float(thr[l])))
+    assert torch.equal(ops.threshold_fwd(xi.to(DEV), thr[:1], False, 3).cpu(), O.topk_inference(xi, 0.3))
+    assert torch.equal(ops.mask_positive(fb.to(DEV), two).cpu(), O.topk_bwd(fb, two.cpu()))
+
+
+def test_losses_and_bookkeeping(ops):
+    B, L, d, F = 37, 3, 20, 48
+    r, y = _rand(B, L, d, seed=1), _rand(B, 2, L, d, seed=2)
+    mean, std = _rand(L, d, seed=3), torch.rand(L, d) + 0.5
+    ls, g, ys = ops.mse(r.to(DEV), y.to(DEV)[:, 1], mean.to(DEV), std.to(DEV), True, True)
+    ysr = O.standardize(y[:, 1], mean, std)
+    diff = (r - ysr).double()
+    assert_close(ls[0] / diff.numel(), (diff ** 2).mean(), 1e-6, 0, "mse")
+    assert_close(g, 2 * diff / diff.numel(), 1e-5, 1e-9, "g"); assert torch.equal(ys.cpu(), ysr)
+    ar = _rand(B, L, d, seed=4); ar[0, 0, 0] = float("nan"); ar[1, 1, 1] = float("inf")
+    gm = g.clone()
+    s, ga = ops.aux_mse(ar.to(DEV), ys, r.to(DEV), gm, 0.25)
+    e = ar - (ysr - r)
+    aux = torch.nan_to_num(e * e, 0.0)
+    assert_close(s[0] / e.numel(), aux.double().mean(), 1e-6, 0, "aux")
+    gref = (0.25 * 2 / e.numel()) * e * torch.isfinite(e * e); gref[~torch.isfinite(e * e)] = 0
+    assert_close(ga, gref, 1e-5, 1e-9, "g_aux"); assert_close(gm, g.cpu() + gref, 1e-5, 1e-9, "g_main")
+    # JumpReLU module loss terms + fused backward vs the oracle formulas
+    pre = _rand(B, L, F, seed=5, scale=0.2); theta = torch.full((1, L, F), 0.05) + _rand(1, L, F, seed=6, scale=0.02)
+    Ws = [_rand(l + 1, F, d, seed=20 + l, scale=0.3) for l in range(L)]
+    sq = torch.zeros(L * F, device=DEV)
+    for l in range(L):
+        ops.row_sqnorm(Ws[l].to(DEV), sq, 0, True)
+    n = O.decoder_norms({f"decoder.W_{l}": Ws[l] for l in range(L)}, "clt", L)
+    assert_close(sq.sqrt().reshape(1, L, F), n, 1e-5, 1e-7, "dec_norms")
+    dfm = _rand(B, L, F, seed=7, scale=0.01)
+    lam, c, coef, bw = 0.3 / B, 0.7, 1e-2 / (B * L), 0.04
+    for use_tanh in (True, False):
+        sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre.to(DEV), theta.to(DEV), sq, dfm.to(DEV), bw, lam, c, use_tanh, coef)
+        f = O.jumprelu_fwd(pre, theta); w = f * n * c; t = torch.tanh(w) if use_tanh else w
+        dt = 1 - t * t if use_tanh else torch.ones_like(t)
+        df = dfm + lam * dt * c * n
+        dxr, dthr = O.jumprelu_bwd(pre, theta, bw, df)
+        assert_close(sums[0], t.double().sum(), 1e-6, 1e-9); assert_close(sums[1], torch.relu(-pre).double().sum(), 1e-6, 0)
+        assert_close(sums[2], w.double().sum(), 1e-6, 1e-9)
+        assert_close(dpre, dxr - coef * (pre < 0), 1e-5, 1e-9, "dpre")
+        assert_close(dth, dthr, 1e-4, 1e-5 * float(dthr.abs().max()), "dtheta")
+        assert_close(dn.reshape(L, F), (lam * dt * c * f).sum(0), 1e-4, 1e-8, "dnorm")
+    dW = _rand(L, F, d, seed=9).to(DEV); dW0 = dW.clone().cpu()
+    ops.rowscale_add(Ws[L - 1].to(DEV), dn, sq, dW)
+    assert_close(dW, dW0 + (dn.cpu() / sq.cpu().sqrt()).reshape(L, F, 1) * Ws[L - 1], 1e-5, 1e-7, "rowscale")
+    # dead features
+    feat = torch.relu(_rand(B, L, F, seed=11) - 1.5)
+    la = torch.randint(0, 100, (L, F)); lad = la.clone().to(DEV)
+    dead, cnt = ops.dead_update(ops.column_any_positive(feat.to(DEV)), B, lad, 60)
+    lar, deadr = O.update_dead_features(la, feat, 60)
+    assert torch.equal(lad.cpu(), lar) and torch.equal(dead.cpu().bool(), deadr) and int(cnt) == int(deadr.sum())
+
+
+def test_adam(ops):
+    n = 1000 * 37 + 3
+    p, g = _rand(n, seed=1), _rand(n, seed=2, scale=0.01)
+    for adamw, wd in ((False, 0.0), (True, 0.01)):
+        pd, m, v = p.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+        sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        for step in range(1, 4):
+            gs = g * step
+            ops.adam(pd, gs.to(DEV), m, v, step, 1e-3, 0.9, 0.999, 1e-8, wd, adamw, sh)
+            pr, mr, vr = O.adam_step(pr, gs, mr, vr, step, 1e-3, 0.9, 0.999, 1e-8, wd, adamw)
+        assert_close(pd, pr, 1e-6, 1e-7, "p"); assert_close(m, mr, 1e-5, 1e-9, "m"); assert_close(v, vr, 1e-5, 1e-12, "v")
+        assert torch.equal(sh.cpu(), pd.cpu().to(torch.bfloat16))
