@@ -34,7 +34,7 @@ SIGNATURES = {
     "clt_topk_rows_f32": (I, [P, P, I, I, I, P, P, P]),
     "clt_topk_segmented_workspace_bytes": (SZ, [I, I, I, I]),
     "clt_topk_segmented_f32": (I, [P, P, I, I, I, I, I, P, F32, P, SZ, P]),
-    "clt_mask_positive_f32": (I, [P, P, P, L, P]),
+    "clt_mask_positive_f32": (I, [P, P, P, L, I, P]),
     "clt_threshold_fwd_f32": (I, [P, P, I, P, I, I, I, P]),
     "clt_mask_dead_f32": (I, [P, P, P, I, I, P]),
     "clt_reduce_workspace_bytes": (SZ, [L]),
@@ -48,7 +48,7 @@ SIGNATURES = {
     "clt_rowscale_add_f32": (I, [P, P, P, P, I, I, P]),
     "clt_column_any_positive_f32": (I, [P, I, I, P, P]),
     "clt_dead_update": (I, [P, I, L, P, L, P, P, P]),
-    "clt_adam_f32": (I, [P, P, P, P, L, F32, F32, F32, F32, F32, I, I, P, P]),
+    "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P]),
 }
 
 ABI_VERSION = 1

@@ -79,9 +79,12 @@ __global__ void relu_bwd_kernel(const float* __restrict__ x, const float* __rest
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         dx[i] = x[i] > 0.0f ? g[i] : 0.0f;
 }
-__global__ void mask_positive_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ dx, long n) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dx[i] = f[i] > 0.0f ? g[i] : 0.0f;
+__global__ void mask_positive_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ dx, long n,
+                                     int accumulate) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = f[i] > 0.0f ? g[i] : 0.0f;
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
 }
 __global__ void jumprelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ theta, float* __restrict__ o,
                                     long total, int n) {
@@ -303,12 +306,12 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
 
 // ---- K13 --------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n4, long n, float lr, float b1, float b2, float eps, float wd, int adamw,
+                            long n4, long n, float lr, float omb1, float b2, float omb2, float eps, float wd, int adamw,
                             float step_size, float inv_sqrt_bc2, uint16_t* __restrict__ sh) {
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
-        mm = mm + (gg - mm) * (1.0f - b1);
-        vv = vv * b2 + (1.0f - b2) * gg * gg;
+        mm = mm + (gg - mm) * omb1;
+        vv = vv * b2 + omb2 * gg * gg;
         const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
         pp -= step_size * (mm / denom);
     };
@@ -367,9 +370,9 @@ int clt_relu_bwd_f32(const float* x, const float* g, float* dx, long n, void* st
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), x, g, dx, n);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
-int clt_mask_positive_f32(const float* f, const float* g, float* dx, long n, void* st) {
+int clt_mask_positive_f32(const float* f, const float* g, float* dx, long n, int accumulate, void* st) {
     if (n <= 0) return CLT_ERR_SHAPE;
-    hipLaunchKernelGGL(mask_positive_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), f, g, dx, n);
+    hipLaunchKernelGGL(mask_positive_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), f, g, dx, n, accumulate);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_jumprelu_fwd_f32(const float* x, const float* theta, float* o, int rows, int n, void* st) {
@@ -488,15 +491,15 @@ int clt_cast_transpose_bf16(const float* in, long ldi, uint16_t* out, long ldo, 
                        in, ldi, out, ldo, rows, cols, s_in, s_out);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
-int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, double wd,
                  int adamw, int step, uint16_t* shadow, void* st) {
     if (n <= 0 || step < 1) return CLT_ERR_SHAPE;
-    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    const float step_size = (float)((double)lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const float step_size = (float)(lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
     const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
     const long n4 = vec ? n / 4 : 0;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
-                       lr, b1, b2, eps, wd, adamw, step_size, isb2, shadow);
+                       (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 }  // extern "C"

@@ -1,0 +1,186 @@
+"""Training modules with the reference's class names, constructor kwargs and `training_step` /
+`configure_optimizers` contract (reference model/clt_lightning.py:29-567), running the fused HIP engine.
+
+If `lightning` is importable the classes derive from `lightning.LightningModule`; otherwise from a small
+stand-in base (nn.Module + log / global_step / trainer) so that the same code runs under
+crosslayer_transcoder_amd.trainer.fit — Lightning is not installed in the build image.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..optim import FusedAdam
+from .clt import CrossLayerTranscoder
+
+try:                                                   # pragma: no cover - not installed in the build image
+    import lightning as _L
+    _Base = _L.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:                                      # noqa: BLE001
+    HAVE_LIGHTNING = False
+
+    class _Trainer:
+        max_steps = 1
+        num_devices = 1
+
+    class _Base(nn.Module):
+        """What training_step touches of LightningModule: log(), global_step, trainer."""
+
+        def __init__(self, *args, **kwargs):
+            super().__init__()
+            self.logged = {}
+            self.global_step = 0
+            self.trainer = _Trainer()
+
+        def log(self, name, value, *args, **kwargs):
+            self.logged[name] = value
+
+        def save_hyperparameters(self, *args, **kwargs):
+            pass
+
+
+class _StepLoss(torch.autograd.Function):
+    """Connects the engine's explicit gradients to `loss.backward()`: forward returns the loss value,
+    backward hands each parameter its precomputed gradient (scaled by the incoming grad when it is not
+    the unit root gradient, e.g. under a loss scaler)."""
+
+    @staticmethod
+    def forward(ctx, loss, unit_root, *params_and_grads):
+        n = len(params_and_grads) // 2
+        ctx.grads = params_and_grads[n:]
+        ctx.unit_root = unit_root
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        gs = ctx.grads if ctx.unit_root else tuple(g * gout for g in ctx.grads)
+        return (None, None) + tuple(gs) + (None,) * len(gs)
+
+
+class CrossLayerTranscoderModule(_Base):
+    _loss_kind = "base"
+
+    def __init__(self, model: CrossLayerTranscoder, replacement_model=None, dead_features=None,
+                 learning_rate: float = 1e-3, compile: bool = False, warmup_steps: int = 0, lr_decay_step: int = 0,
+                 lr_decay_factor: float = 1.0, compute_dead_features: bool = False,
+                 compute_dead_features_every: int = 100, tokens_till_dead: int = 1_000_000, optimizer: str = "adam",
+                 beta1: Optional[float] = None, beta2: Optional[float] = None, log_metrics_every: int = 50,
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.model = model
+        self.replacement_model = replacement_model      # eval-time metric objects are accepted and ignored
+        self.dead_features = dead_features
+        self.learning_rate = learning_rate
+        self.compile = compile                          # torch.compile flag: no-op here (kernels are hand-written)
+        self.tokens_till_dead = tokens_till_dead
+        self.warmup_steps, self.lr_decay_step, self.lr_decay_factor = warmup_steps, lr_decay_step, lr_decay_factor
+        self.compute_dead_features = compute_dead_features
+        self.compute_dead_features_every = compute_dead_features_every
+        self.optimizer, self.beta1, self.beta2 = optimizer, beta1, beta2
+        self.log_metrics_every = log_metrics_every
+        #: loss.backward() is assumed to start from the unit gradient (Lightning's "32"/"bf16-mixed" paths);
+        #: set False when a loss scaler multiplies the loss.
+        self.assume_unit_loss_grad = True
+        assert model.encoder.n_layers == model.decoder.n_layers, "Encoder and decoder must have the same number of layers"
+        self.register_buffer("last_active", torch.zeros((model.encoder.n_layers, model.encoder.d_features),
+                                                        dtype=torch.long))
+        self.last_step = None
+
+    def configure_model(self):
+        pass
+
+    def forward(self, acts_norm):
+        return self.model(acts_norm)
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def _named_model_params(self):
+        return dict(self.model.named_parameters())
+
+    def _log_terms(self, terms):
+        names = {"loss": "training/loss", "sparsity": "training/sparsity_loss", "pre_actv": "training/pre_actv_loss",
+                 "aux": "training/aux_loss", "dead_fraction": "metrics/dead_features", "mse": "metrics/train_mse",
+                 "sparsity_penalty": "training/sparsity_penalty",
+                 "weighted_features_mean": "model/weighted_features_mean"}
+        for k, v in terms.items():
+            self.log(names.get(k, k), v)
+
+    def compute_step(self, batch, batch_idx):
+        """Loss + gradients through the fused engine (no autograd).  Result kept in `self.last_step`."""
+        with torch.no_grad():
+            out = engine.training_step(self, batch, batch_idx)
+        self.last_step = out
+        self._log_terms(out["terms"])
+        return out
+
+    def training_step(self, batch, batch_idx):
+        out = self.compute_step(batch, batch_idx)
+        params = self._named_model_params()
+        names = [n for n in params if n in out["grads"]]
+        ps = [params[n] for n in names]
+        gs = [out["grads"][n].reshape(params[n].shape) for n in names]
+        return _StepLoss.apply(out["loss"], self.assume_unit_loss_grad, *ps, *gs)
+
+    def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None):
+        """fwd + bwd + Adam with no autograd bookkeeping: what bench.py times."""
+        out = self.compute_step(batch, batch_idx)
+        params = self._named_model_params()
+        for n, p in params.items():
+            g = out["grads"].get(n)
+            p.grad = None if g is None else g.reshape(p.shape)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        self.global_step += 1
+        return out["loss"]
+
+    def validation_step(self, batch, batch_idx):
+        pass
+
+    def configure_optimizers(self):
+        b1 = 0.9 if self.beta1 is None else self.beta1
+        b2 = 0.999 if self.beta2 is None else self.beta2
+        if self.optimizer == "adam":
+            opt = FusedAdam(self.parameters(), lr=self.learning_rate, betas=(b1, b2))
+        elif self.optimizer == "adamw":
+            opt = FusedAdam(self.parameters(), lr=self.learning_rate, betas=(b1, b2), weight_decay=0.01, adamw=True)
+        else:
+            raise ValueError(f"Optimizer {self.optimizer} not supported")
+        sched = None
+        if self.warmup_steps > 0:
+            sched = ("warmup", torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-7, end_factor=1.0,
+                                                                 total_iters=self.warmup_steps))
+        elif self.lr_decay_step > 0:
+            sched = ("step_decay", torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[self.lr_decay_step],
+                                                                       gamma=self.lr_decay_factor))
+        if sched is None:
+            return opt
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched[1], "interval": "step", "frequency": 1,
+                                                   "name": sched[0]}}
+
+
+class JumpReLUCrossLayerTranscoderModule(CrossLayerTranscoderModule):
+    _loss_kind = "jumprelu"
+
+    def __init__(self, lambda_sparsity: float = 0.0002, c_sparsity: float = 0.1, use_tanh: bool = True,
+                 pre_actv_loss: float = 0.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._lambda = lambda_sparsity
+        self.c = c_sparsity
+        self.use_tanh = use_tanh
+        self.pre_actv_loss = pre_actv_loss
+
+    def current_sparsity_penalty(self):
+        return self._lambda * (self.global_step / self.trainer.max_steps)
+
+
+class TopKCrossLayerTranscoderModule(CrossLayerTranscoderModule):
+    _loss_kind = "topk"
+
+    def __init__(self, topk_aux: nn.Module, tokens_till_dead: int = 100_000, aux_loss_scale: float = 1 / 32,
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tokens_till_dead = tokens_till_dead
+        self.topk_aux = topk_aux
+        self.aux_loss_scale = aux_loss_scale

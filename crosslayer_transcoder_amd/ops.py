@@ -263,9 +263,10 @@ def topk_segmented(x, k: int, per_layer: bool, threshold: Optional[torch.Tensor]
     return feat
 
 
-def mask_positive(feat, g):
-    dx = torch.empty_like(_chk(feat))
-    call("clt_mask_positive_f32", feat.data_ptr(), _chk(g).data_ptr(), dx.data_ptr(), feat.numel(), _stream())
+def mask_positive(feat, g, out=None, accumulate=False):
+    dx = torch.empty_like(_chk(feat)) if out is None else _chk(out)
+    call("clt_mask_positive_f32", feat.data_ptr(), _chk(g).data_ptr(), dx.data_ptr(), feat.numel(), int(accumulate),
+         _stream())
     return dx
 
 

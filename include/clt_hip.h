@@ -96,8 +96,9 @@ int clt_topk_rows_f32(const float* x, float* feat_out, int rows, int F, int k, i
 size_t clt_topk_segmented_workspace_bytes(int B, int L, int F, int per_layer);
 int clt_topk_segmented_f32(const float* x, float* feat_out, int B, int L, int F, int k, int per_layer,
                            float* threshold, float ema_e, void* workspace, size_t ws_bytes, void* stream);
-/* backward of scatter(relu(gather)): dx = g * [feat > 0]. */
-int clt_mask_positive_f32(const float* feat, const float* g, float* dx, long count, void* stream);
+/* backward of scatter(relu(gather)): dx (+)= g * [feat > 0]. */
+int clt_mask_positive_f32(const float* feat, const float* g, float* dx, long count, int accumulate,
+                          void* stream);
 /* inference path (topk.py:71-74, 104-107): out = x > max(thr[seg],0) ? x : 0, seg = 0 or layer. */
 int clt_threshold_fwd_f32(const float* x, const float* threshold, int per_layer, float* out, int B, int L,
                           int F, void* stream);
@@ -157,10 +158,11 @@ int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* last_acti
 
 /* ---------------------------------------------------------------------------------------------
  * K13  fused Adam / AdamW — clt_lightning.py:339-352 (torch.optim semantics, eps outside sqrt)
- * step counts from 1.  bf16_shadow (optional) receives the updated weights rounded to bf16.
+ * step counts from 1; hyper-parameters are doubles (torch derives 1-beta and the bias corrections in
+ * double before rounding to fp32).  bf16_shadow (optional) receives the updated weights rounded to bf16.
  * ------------------------------------------------------------------------------------------- */
-int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int adamw, int step, uint16_t* bf16_shadow,
+int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int adamw, int step, uint16_t* bf16_shadow,
                  void* stream);
 
 #ifdef __cplusplus
