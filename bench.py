@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: activation tokens/s of one crosslayer-transcoder training step (fwd + bwd + Adam),
+GPT-2-small CLT, 32k features per layer, BatchTopK(k=16), synthetic activations resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for what `roofline` and `cpu_baseline` mean.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
+
+
+def synth_batch(B, L, d, device, seed=42):
+    """batch[:,0] ~ N(0,1); batch[:,1] = 0.5*batch[:,0]*A + 0.1*N(0,1)  (BASELINE.md §3)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(B, L, d, device=device, generator=g)
+    A = torch.randn(L, d, device=device, generator=g)
+    y = 0.5 * x * A + 0.1 * torch.randn(B, L, d, device=device, generator=g)
+    return torch.stack([x, y], dim=1).contiguous()
+
+
+def build(args, device):
+    from crosslayer_transcoder_amd.model import BatchTopK, CrossLayerTranscoder, CrosslayerDecoder, Encoder, PerLayerTopK
+    from crosslayer_transcoder_amd.model.clt_lightning import CrossLayerTranscoderModule, TopKCrossLayerTranscoderModule
+    from crosslayer_transcoder_amd.model.standardize import DimensionwiseInputStandardizer, DimensionwiseOutputStandardizer
+    L, d, F = args.layers, args.d_acts, args.features
+    torch.manual_seed(42)
+    with torch.device(device):
+        model = CrossLayerTranscoder(BatchTopK(k=args.k, e=0.01), Encoder(d, F, L), CrosslayerDecoder(d, F, L),
+                                     DimensionwiseInputStandardizer(L, d), DimensionwiseOutputStandardizer(L, d))
+        if args.aux:
+            mod = TopKCrossLayerTranscoderModule(model=model, topk_aux=PerLayerTopK(k=512), learning_rate=1e-4,
+                                                 tokens_till_dead=args.batch * 3)
+        else:
+            mod = CrossLayerTranscoderModule(model=model, learning_rate=1e-4)
+    mod.trainer.max_steps = 100_000
+    return mod.to(device)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a restatement of the reference's fp32 path) on a bounded sample of the same
+    workload: full model shape, reduced batch, one step of loss + gradients + Adam."""
+    from oracle import clt_oracle as O
+    L, d, F, Bc = args.layers, args.d_acts, args.features, args.cpu_batch
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(42)
+    bound_e, bound_d = 1 / F ** 0.5, 1 / (d * L) ** 0.5
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * bound_e, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * bound_d
+    batch = synth_batch(Bc, L, d, "cpu")
+    cfg = {"decoder": "clt", "nonlinearity": {"kind": "batchtopk", "k": args.k, "e": 0.01}, "loss": {"kind": "base"}}
+    buffers = {"last_active": torch.zeros(L, F, dtype=torch.long), "threshold": torch.zeros(1)}
+    std = O.standardizer_init(batch)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(p) for k, p in params.items()}
+    t0 = time.perf_counter()
+    out = O.training_step(batch, params, std, cfg, buffers)
+    for k in params:
+        params[k], m[k], v[k] = O.adam_step(params[k], out["grads"][k], m[k], v[k], 1, 1e-4)
+    dt = time.perf_counter() - t0
+    return {"value": Bc / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"1 step (loss+grads+Adam) of the CPU oracle, fp32, full model shape L={L} d={d} F={F}, "
+                      f"batch {Bc} tokens, {threads} torch threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--features", type=int, default=32768)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--d-acts", type=int, default=768)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--aux", action="store_true", help="TopK module with the k_aux=512 dead-feature loss")
+    ap.add_argument("--precision", default="bf16-mixed")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import crosslayer_transcoder_amd as cta
+    cta.set_precision(args.precision)
+    mod = build(args, device)
+    opt = mod.configure_optimizers()
+    batch = synth_batch(args.batch, args.layers, args.d_acts, device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        mod.fused_train_step(batch, step, opt)
+        step += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mod.fused_train_step(batch, step, opt)
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms = dt / args.steps * 1e3
+    tokens_per_s = args.batch * args.steps / dt      # feature-sharded: every rank sees the same tokens
+
+    L, d, F = args.layers, args.d_acts, args.features
+    line = {
+        "metric": "activation tokens/sec (fwd+bwd+Adam), GPT-2 CLT 32k feats, 1/2/4/8 MI355X",
+        "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
+        "config": {"workload": f"gpt2-small CLT BatchTopK(k={args.k}) L={L} d={d} F={F}/layer B={args.batch}"
+                               + (" +aux(k=512)" if args.aux else ""),
+                   "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
+                   "loss": float(mod.last_step["loss"])},
+    }
+    if rank == 0:
+        try:
+            import bench_roofline
+            line["roofline"] = bench_roofline.measure(mod, batch, args)
+        except Exception as e:                                   # noqa: BLE001
+            line["roofline"] = None
+            line["roofline_error"] = repr(e)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
