@@ -48,6 +48,13 @@ SIGNATURES = {
     "clt_rowscale_add_f32": (I, [P, P, P, P, I, I, P]),
     "clt_column_any_positive_f32": (I, [P, I, I, P, P]),
     "clt_dead_update": (I, [P, I, L, P, L, P, P, P]),
+    "clt_sparse_build_workspace_bytes": (SZ, [I, I, I]),
+    "clt_sparse_build_f32": (I, [P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, P]),
+    "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P]),
+    "clt_sparse_reduce_dots_f32": (I, [P, L, P, I, I, I, P, P]),
+    "clt_sparse_scatter_dense_f32": (I, [P, P, P, I, I, P, P]),
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P]),
 }
 

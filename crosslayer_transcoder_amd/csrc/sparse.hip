@@ -1,0 +1,477 @@
+// Sparse (activation-list) decoder path of the crosslayer-transcoder step for gfx950.
+//
+// When the sparsifier leaves k << F active features per (token, layer) the reference still runs dense
+// bmm's over [B, (l+1)F] x [(l+1)F, d] (model/clt.py:334-343) and their autograd.  Here the active
+// entries are compacted once into a token-major CSR and a feature-major CSC list, and
+//   * forward   : recons[b,l,:] = b[l] + sum_{entries (l',i,val) of token b, l' <= l} val * W_l[l',i,:]
+//   * backward  : one streaming pass over every decoder row W_l[l',i,:] that (a) forms the row's weight
+//                 gradient  sum_b val * g[b,l,:]  from the feature's token list, (b) emits the partial
+//                 d(loss)/d(feature) dots  g[b,l,:] . W_l[l',i,:]  for those tokens, and (c) applies the
+//                 Adam update in the same pass — so the dense dW tensor never exists in HBM.
+// All kernels are HBM/L2-bandwidth bound (row gathers of d floats); lists are ordered, so every sum has a
+// fixed order and results are bitwise reproducible.
+#include <math.h>
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------
+// list construction
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void count_rows_kernel(const float* __restrict__ feat, int F, uint32_t* __restrict__ row_cnt) {
+    __shared__ uint32_t sh[4];
+    const float* xr = feat + (long)blockIdx.x * F;
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < F; i += TPB) c += xr[i] > 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ start,
+                                                     uint32_t* __restrict__ total, uint8_t* __restrict__ fired) {
+    __shared__ uint32_t sh[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? cnt[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t s = sh[k]; if (k < w) wbase += s; tot += s; }
+        const uint32_t c0 = carry;
+        if (i < n) { start[i] = c0 + wbase + inc - v; if (fired) fired[i] = v > 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c0 + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { start[n] = carry; if (total) *total = carry; }
+}
+
+// ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row
+__global__ __launch_bounds__(TPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L,
+                                                        const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
+                                                        float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow) {
+    __shared__ uint32_t wcnt[4];
+    const long row = blockIdx.x;
+    const float* xr = feat + row * F;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = ((F + 3) / 4 + 63) / 64 * 64;
+    const int s0 = w * seg, s1 = min(F, s0 + seg);
+    uint32_t c = 0;
+    for (int i = s0 + lane; i < s1; i += 64) c += xr[i] > 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) wcnt[w] = c;
+    __syncthreads();
+    uint32_t off = row_start[row];
+    for (int k = 0; k < w; ++k) off += wcnt[k];
+    const int colbase = (int)(row % L) * F;
+    for (int base = s0; base < s1; base += 64) {
+        const int i = base + lane;
+        const float v = i < s1 ? xr[i] : 0.0f;
+        const bool p = v > 0.0f;
+        const unsigned long long m = __ballot(p);
+        if (p) {
+            const uint32_t pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) { ent_col[pos] = colbase + i; ent_val[pos] = v; }
+            else *overflow = 1;
+        }
+        off += __popcll(m);
+    }
+}
+
+__global__ void count_cols_kernel(const int32_t* __restrict__ ent_col, const uint32_t* __restrict__ total, uint32_t cap,
+                                  uint32_t* __restrict__ col_cnt) {
+    const uint32_t n = min(*total, cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
+        atomicAdd(&col_cnt[ent_col[e]], 1u);
+}
+
+// one wave per CSR row: scatter its entries into the CSC lists (order inside a column fixed up by sort)
+__global__ __launch_bounds__(TPB) void fill_cols_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
+                                                        const float* __restrict__ ent_val, int rows, int L, uint32_t cap,
+                                                        const uint32_t* __restrict__ col_start, uint32_t* __restrict__ cursor,
+                                                        int32_t* __restrict__ csc_tok, float* __restrict__ csc_val,
+                                                        int32_t* __restrict__ csc_ent) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t e0 = row_start[row], e1 = min(row_start[row + 1], cap);
+    const int tok = row / L;
+    for (uint32_t e = e0 + (threadIdx.x & 63); e < e1; e += 64) {
+        const int c = ent_col[e];
+        const uint32_t pos = col_start[c] + atomicAdd(&cursor[c], 1u);
+        csc_tok[pos] = tok; csc_val[pos] = ent_val[e]; csc_ent[pos] = (int32_t)e;
+    }
+}
+
+// order each column's entries by token.  Short columns: one thread, insertion sort.  Long columns are
+// queued and sorted by a block (bitonic in LDS) in sort_long_cols_kernel.
+constexpr int SHORT_COL = 24, LONGCOL_MAX = 4096;
+__global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int ncols, int32_t* __restrict__ tok,
+                                 float* __restrict__ val, int32_t* __restrict__ ent, int32_t* __restrict__ long_list,
+                                 uint32_t* __restrict__ long_count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+    if (n < 2) return;
+    if (n > SHORT_COL) { long_list[atomicAdd(long_count, 1u)] = c; return; }
+    for (uint32_t i = 1; i < n; ++i) {
+        const int32_t t = tok[s + i], en = ent[s + i]; const float v = val[s + i];
+        uint32_t j = i;
+        while (j > 0 && tok[s + j - 1] > t) { tok[s + j] = tok[s + j - 1]; val[s + j] = val[s + j - 1]; ent[s + j] = ent[s + j - 1]; --j; }
+        tok[s + j] = t; val[s + j] = v; ent[s + j] = en;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void sort_long_cols_kernel(const uint32_t* __restrict__ col_start, int32_t* __restrict__ tok,
+                                                             float* __restrict__ val, int32_t* __restrict__ ent,
+                                                             const int32_t* __restrict__ long_list,
+                                                             const uint32_t* __restrict__ long_count) {
+    __shared__ unsigned long long key[LONGCOL_MAX];     // (token << 32) | position within the column
+    __shared__ float sval[LONGCOL_MAX];
+    __shared__ int32_t sent[LONGCOL_MAX];
+    const uint32_t nl = *long_count;
+    for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
+        const int c = long_list[q];
+        const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+        if (n > LONGCOL_MAX) continue;                  // left in arrival order (still correct, not bit-reproducible)
+        uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+        for (uint32_t i = threadIdx.x; i < np2; i += TPB) {
+            key[i] = i < n ? (((unsigned long long)(uint32_t)tok[s + i] << 32) | i) : ~0ull;
+            if (i < n) { sval[i] = val[s + i]; sent[i] = ent[s + i]; }
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= np2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < np2; i += TPB) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = (i & k) == 0;
+                        const unsigned long long a = key[i], b = key[ixj];
+                        if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+            const uint32_t src = (uint32_t)(key[i] & 0xffffffffu);
+            tok[s + i] = (int32_t)(key[i] >> 32); val[s + i] = sval[src]; ent[s + i] = sent[src];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward gather: one wave per (token, target layer)
+// ------------------------------------------------------------------------------------------------
+template <int NT, bool VEC>
+__global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
+                                                                 const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, int L, int F,
+                                                                 int d, int cross_layer, uint32_t cap) {
+    constexpr int W = VEC ? 4 : 1;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int l = L - 1 - w; l >= 0; l -= 4) {                 // heaviest layers first, 4 waves interleaved
+        const float* Wl = Wptr[l];
+        const int lo = cross_layer ? 0 : l;
+        const uint32_t e0 = row_start[(long)b * L + lo], e1 = min(row_start[(long)b * L + l + 1], cap);
+        const int colsub = cross_layer ? 0 : l * F;            // per-layer decoder: W[l] rows are indexed by i only
+        float acc[NT][W];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < W; ++c) { const int j = (t * 64 + lane) * W + c; acc[t][c] = (bias && j < d) ? bias[l * d + j] : 0.0f; }
+        for (uint32_t base = e0; base < e1; base += 64) {
+            const uint32_t mine = base + lane;
+            const int mycol = mine < e1 ? ent_col[mine] : 0;
+            const float myval = mine < e1 ? ent_val[mine] : 0.0f;
+            const int cnt = (int)min(64u, e1 - base);
+            for (int j = 0; j < cnt; ++j) {
+                const int col = __shfl(mycol, j, 64) - colsub;
+                const float v = __shfl(myval, j, 64);
+                const float* row = Wl + (long)col * d;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int o = (t * 64 + lane) * W;
+                    if (o < d) {
+                        if (VEC) {
+                            const float4 r = *reinterpret_cast<const float4*>(row + o);
+                            acc[t][0] += v * r.x; acc[t][1 % W] += v * r.y; acc[t][2 % W] += v * r.z; acc[t][3 % W] += v * r.w;
+                        } else acc[t][0] += v * row[o];
+                    }
+                }
+            }
+        }
+        float* dst = out + ((long)b * L + l) * d;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (t * 64 + lane) * W;
+            if (o < d) {
+                if (VEC) *reinterpret_cast<float4*>(dst + o) = make_float4(acc[t][0], acc[t][1 % W], acc[t][2 % W], acc[t][3 % W]);
+                else dst[o] = acc[t][0];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward row pass: sparse weight gradient (+ partial feature-gradient dots) (+ Adam) per weight row
+// ------------------------------------------------------------------------------------------------
+struct RowPassArgs {
+    float* W; float* m; float* v; uint16_t* shadow; float* grad_out;   // grad_out != null: write dW, no Adam
+    int rows, d, F;
+    int col0;                    // CSC column of row 0 (row r <-> column col0 + r)
+    int src_layer;               // >= 0: fixed source layer; < 0: layer = (col0 + r) / F
+    int L;                       // layers in the source tensors ([B][L][d])
+    const uint32_t* col_start; const int32_t* tok; const float* coef; const float* src;
+    const uint32_t* col_start2; const int32_t* tok2; const float* coef2; const float* src2;   // optional 2nd list
+    float* dot_out; float* dot_out2; long dot_stride, dot_stride2; int dot_slot_base;   // dot_out[slot*dot_stride + csc_pos]; slot_base < 0: slot = src layer - own layer
+    float* colsum_out;           // optional: colsum_out[col] = sum coef (encoder bias gradient)
+    float lr, omb1, b2, omb2, eps, wd, step_size, isb2; int adamw;
+};
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
+    constexpr int W = VEC ? 4 : 1;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.rows) return;
+    const int lane = threadIdx.x & 63;
+    const int col = a.col0 + r;
+    const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
+    const long srs = (long)a.L * a.d;
+    const long ro = (long)r * a.d;
+    float wv[NT][W], g[NT][W];
+    const bool need_w = a.dot_out != nullptr || a.dot_out2 != nullptr || a.grad_out == nullptr;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int o = (t * 64 + lane) * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) { g[t][c] = 0.0f; wv[t][c] = 0.0f; }
+        if (need_w && o < a.d) {
+            if (VEC) { const float4 x = *reinterpret_cast<const float4*>(a.W + ro + o); wv[t][0] = x.x; wv[t][1 % W] = x.y; wv[t][2 % W] = x.z; wv[t][3 % W] = x.w; }
+            else wv[t][0] = a.W[ro + o];
+        }
+    }
+    float csum = 0.0f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t* cs = pass ? a.col_start2 : a.col_start;
+        if (!cs) continue;
+        const int32_t* tk = pass ? a.tok2 : a.tok;
+        const float* cf = pass ? a.coef2 : a.coef;
+        const float* src = (pass ? a.src2 : a.src) + (long)layer * a.d;
+        float* dout = pass ? a.dot_out2 : a.dot_out;
+        const long dstride = pass ? a.dot_stride2 : a.dot_stride;
+        const uint32_t p0 = cs[col], p1 = cs[col + 1];
+        for (uint32_t p = p0; p < p1; ++p) {
+            const float cv = cf[p];
+            const float* srow = src + (long)tk[p] * srs;
+            float dot = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int o = (t * 64 + lane) * W;
+                if (o < a.d) {
+                    if (VEC) {
+                        const float4 s = *reinterpret_cast<const float4*>(srow + o);
+                        g[t][0] += cv * s.x; g[t][1 % W] += cv * s.y; g[t][2 % W] += cv * s.z; g[t][3 % W] += cv * s.w;
+                        dot += s.x * wv[t][0] + s.y * wv[t][1 % W] + s.z * wv[t][2 % W] + s.w * wv[t][3 % W];
+                    } else { const float s = srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
+                }
+            }
+            csum += cv;
+            if (dout) {
+                dot = wave_sum(dot);
+                if (lane == 0) dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p] = dot;
+            }
+        }
+    }
+    if (a.colsum_out && lane == 0) a.colsum_out[col] = csum;
+    if (a.grad_out) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (t * 64 + lane) * W;
+            if (o < a.d) {
+                if (VEC) *reinterpret_cast<float4*>(a.grad_out + ro + o) = make_float4(g[t][0], g[t][1 % W], g[t][2 % W], g[t][3 % W]);
+                else a.grad_out[ro + o] = g[t][0];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int o = (t * 64 + lane) * W;
+        if (o >= a.d) continue;
+        float mm[W], vv[W];
+        if (VEC) {
+            const float4 x = *reinterpret_cast<const float4*>(a.m + ro + o); mm[0] = x.x; mm[1 % W] = x.y; mm[2 % W] = x.z; mm[3 % W] = x.w;
+            const float4 y = *reinterpret_cast<const float4*>(a.v + ro + o); vv[0] = y.x; vv[1 % W] = y.y; vv[2 % W] = y.z; vv[3 % W] = y.w;
+        } else { mm[0] = a.m[ro + o]; vv[0] = a.v[ro + o]; }
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            float gg = g[t][c], pp = wv[t][c];
+            if (a.wd != 0.0f) { if (a.adamw) pp *= (1.0f - a.lr * a.wd); else gg += a.wd * pp; }
+            mm[c] = mm[c] + (gg - mm[c]) * a.omb1;
+            vv[c] = vv[c] * a.b2 + a.omb2 * gg * gg;
+            pp -= a.step_size * (mm[c] / (sqrtf(vv[c]) * a.isb2 + a.eps));
+            wv[t][c] = pp;
+        }
+        if (VEC) {
+            *reinterpret_cast<float4*>(a.W + ro + o) = make_float4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
+            *reinterpret_cast<float4*>(a.m + ro + o) = make_float4(mm[0], mm[1 % W], mm[2 % W], mm[3 % W]);
+            *reinterpret_cast<float4*>(a.v + ro + o) = make_float4(vv[0], vv[1 % W], vv[2 % W], vv[3 % W]);
+            if (a.shadow) { ushort4 h; h.x = f32_to_bf16(wv[t][0]); h.y = f32_to_bf16(wv[t][1 % W]); h.z = f32_to_bf16(wv[t][2 % W]); h.w = f32_to_bf16(wv[t][3 % W]);
+                            *reinterpret_cast<ushort4*>(a.shadow + ro + o) = h; }
+        } else {
+            a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[0]; a.v[ro + o] = vv[0];
+            if (a.shadow) a.shadow[ro + o] = f32_to_bf16(wv[t][0]);
+        }
+    }
+}
+
+// dval[p] = sum_{s < nslots(p)} dots[s*stride + p], nslots = L - layer(column of p) (cross-layer) or 1
+__global__ void reduce_dots_kernel(const float* __restrict__ dots, long stride, const uint32_t* __restrict__ col_start, int ncols,
+                                   int F, int L, int cross_layer, float* __restrict__ dval) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const int ns = cross_layer ? L - c / F : 1;
+    for (uint32_t p = col_start[c]; p < col_start[c + 1]; ++p) {
+        float s = 0.0f;
+        for (int k = 0; k < ns; ++k) s += dots[(long)k * stride + p];
+        dval[p] = s;
+    }
+}
+
+// dense [rows][n] gradient of the sparsifier input from CSC-ordered values (for the un-fused autograd path)
+__global__ void scatter_dense_kernel(const uint32_t* __restrict__ col_start, const int32_t* __restrict__ tok, const float* __restrict__ val,
+                                     int ncols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    for (uint32_t p = col_start[c]; p < col_start[c + 1]; ++p) out[(long)tok[p] * ncols + c] = val[p];
+}
+
+}  // namespace
+
+// dispatch on the number of 64-lane chunks a row needs
+#define DISPATCH_NT(KERNEL, GRID, STREAM, D, VECOK, ...)                                                         \
+    do {                                                                                                          \
+        const int chunks_ = ((D) + ((VECOK) ? 256 : 64) - 1) / ((VECOK) ? 256 : 64);                              \
+        if (VECOK) {                                                                                              \
+            if (chunks_ <= 1) hipLaunchKernelGGL((KERNEL<1, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);       \
+            else if (chunks_ <= 2) hipLaunchKernelGGL((KERNEL<2, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);  \
+            else if (chunks_ <= 3) hipLaunchKernelGGL((KERNEL<3, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);  \
+            else if (chunks_ <= 4) hipLaunchKernelGGL((KERNEL<4, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);  \
+            else if (chunks_ <= 8) hipLaunchKernelGGL((KERNEL<8, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);  \
+            else if (chunks_ <= 16) hipLaunchKernelGGL((KERNEL<16, true>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__); \
+            else return CLT_ERR_RANGE;                                                                            \
+        } else {                                                                                                  \
+            if (chunks_ <= 1) hipLaunchKernelGGL((KERNEL<1, false>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__);      \
+            else if (chunks_ <= 2) hipLaunchKernelGGL((KERNEL<2, false>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__); \
+            else if (chunks_ <= 4) hipLaunchKernelGGL((KERNEL<4, false>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__); \
+            else if (chunks_ <= 16) hipLaunchKernelGGL((KERNEL<16, false>), GRID, dim3(TPB), 0, STREAM, __VA_ARGS__); \
+            else return CLT_ERR_RANGE;                                                                            \
+        }                                                                                                         \
+    } while (0)
+
+extern "C" {
+
+// workspace layout of clt_sparse_build: row_cnt[rows] | col_cnt[ncols] | cursor[ncols] | long_list[ncols] | long_count
+size_t clt_sparse_build_workspace_bytes(int B, int L, int F) {
+    const size_t rows = (size_t)B * L, ncols = (size_t)L * F;
+    return (rows + 3 * ncols + 64) * sizeof(uint32_t);
+}
+
+int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
+                         float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
+                         uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, void* stp) {
+    if (B <= 0 || L <= 0 || F <= 0 || cap == 0) return CLT_ERR_SHAPE;
+    if ((unsigned long long)L * F >= 0x7fffffffull || (unsigned long long)B * L >= 0x7fffffffull) return CLT_ERR_RANGE;
+    if (!ws || wsb < clt_sparse_build_workspace_bytes(B, L, F)) return CLT_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stp);
+    const int rows = B * L, ncols = L * F;
+    uint32_t* row_cnt = (uint32_t*)ws;
+    uint32_t* col_cnt = row_cnt + rows;
+    uint32_t* cursor = col_cnt + ncols;
+    int32_t* long_list = (int32_t*)(cursor + ncols);
+    uint32_t* long_count = (uint32_t*)(long_list + ncols);
+    if (hipMemsetAsync(col_cnt, 0, (size_t)2 * ncols * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, row_cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, row_start, ent_col, ent_val, cap, overflow);
+    hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, col_start, (uint32_t*)nullptr, fired);
+    hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
+                       col_start, cursor, csc_tok, csc_val, csc_ent);
+    hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val,
+                       csc_ent, long_list, long_count);
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
+                       long_count);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,
+                               const float* bias, float* out, int B, int L, int F, int d, int cross_layer, uint32_t cap,
+                               void* stp) {
+    if (B <= 0 || L <= 0 || F <= 0 || d <= 0) return CLT_ERR_SHAPE;
+    const bool vec = d % 4 == 0 && aligned16(out);
+    DISPATCH_NT(sparse_decoder_fwd_kernel, dim3(B), as_stream(stp), d, vec, row_start, ent_col, ent_val, Wptr, bias, out, L, F, d,
+                cross_layer, cap);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F, int L,
+                            int col0, int src_layer, const uint32_t* col_start, const int32_t* tok, const float* coef,
+                            const float* src, const uint32_t* col_start2, const int32_t* tok2, const float* coef2,
+                            const float* src2, float* dot_out, float* dot_out2, long dot_stride, long dot_stride2, int dot_slot,
+                            float* colsum_out,
+                            double lr,
+                            double beta1, double beta2, double eps, double weight_decay, int adamw, int step, void* stp) {
+    if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
+    if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
+    RowPassArgs a;
+    a.W = W; a.m = m; a.v = v; a.shadow = shadow; a.grad_out = grad_out; a.rows = rows; a.d = d; a.F = F; a.col0 = col0;
+    a.src_layer = src_layer; a.L = L; a.col_start = col_start; a.tok = tok; a.coef = coef; a.src = src;
+    a.col_start2 = col_start2; a.tok2 = tok2; a.coef2 = coef2; a.src2 = src2; a.dot_out = dot_out; a.dot_out2 = dot_out2; a.dot_stride = dot_stride; a.dot_stride2 = dot_stride2;
+    a.dot_slot_base = dot_slot; a.colsum_out = colsum_out;
+    const int s = step < 1 ? 1 : step;
+    const double bc1 = 1.0 - pow(beta1, s), bc2 = 1.0 - pow(beta2, s);
+    a.lr = (float)lr; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.wd = (float)weight_decay; a.step_size = (float)(lr / bc1); a.isb2 = (float)(1.0 / sqrt(bc2)); a.adamw = adamw;
+    const bool vec = d % 4 == 0 && aligned16(W) && aligned16(src) && (!m || aligned16(m)) && (!v || aligned16(v)) &&
+                     (!grad_out || aligned16(grad_out)) && (!src2 || aligned16(src2)) &&
+                     (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
+    DISPATCH_NT(row_pass_kernel, dim3((rows + 3) / 4), as_stream(stp), d, vec, a);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_reduce_dots_f32(const float* dots, long stride, const uint32_t* col_start, int L, int F, int cross_layer,
+                               float* dval, void* stp) {
+    if (L <= 0 || F <= 0) return CLT_ERR_SHAPE;
+    const int ncols = L * F;
+    hipLaunchKernelGGL(reduce_dots_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), dots, stride, col_start,
+                       ncols, F, L, cross_layer, dval);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_scatter_dense_f32(const uint32_t* col_start, const int32_t* tok, const float* val, int B, int ncols, float* out,
+                                 void* stp) {
+    if (B <= 0 || ncols <= 0) return CLT_ERR_SHAPE;
+    if (hipMemsetAsync(out, 0, (size_t)B * ncols * sizeof(float), as_stream(stp)) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(scatter_dense_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), col_start, tok, val,
+                       ncols, out);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+}  // extern "C"

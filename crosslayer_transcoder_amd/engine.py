@@ -4,6 +4,14 @@ into the HIP kernels (no autograd graph), in the order the reference's autograd 
 Mirrors, op for op, reference model/clt_lightning.py:290-312 (base), :420-475 (JumpReLU module) and
 :519-567 (TopK module with auxiliary loss).  Gradient formulas are those validated in the CPU oracle
 against the reference's autograd (oracle/clt_oracle.py:training_step — not imported here).
+
+Two regimes:
+  * dense  (ReLU / JumpReLU): encoder, decoder fwd/dgrad/wgrad are MFMA GEMMs; Adam is a separate pass.
+  * sparse (TopK family): after the select the active entries are compacted into token-major (CSR) and
+    feature-major (CSC) lists.  The decoder forward is a row gather; the decoder and encoder backward are
+    ONE streaming pass over each weight matrix that forms the row's gradient from its feature's token list,
+    emits the d(loss)/d(feature) dots and — when an optimizer is handed in — applies Adam in place, so the
+    dense gradient tensors (7.9 GB for the GPT-2 32k CLT) never exist.
 """
 from __future__ import annotations
 
@@ -33,6 +41,21 @@ def _select(nl, pre):
                               nl.e or 0.0)
 
 
+def _encoder_operand(enc):
+    """Feature-major [L,F,d] encoder weight in the active precision.  In bf16 mode a persistent bf16 shadow is
+    kept on the module; the fused Adam row pass refreshes it, any other in-place change of W (optimizer,
+    load_state_dict) bumps the tensor version and triggers a re-cast."""
+    Wt = enc.Wt
+    if get_precision() != "bf16":
+        return Wt
+    sh = getattr(enc, "_bf16_shadow", None)
+    ver = (enc.W._version, getattr(enc.W, "_clt_version", 0), Wt.data_ptr())
+    if sh is None or enc._shadow_version != ver:
+        sh = ops.cast_bf16(Wt)
+        enc._bf16_shadow, enc._shadow_version = sh, ver
+    return sh
+
+
 class _Decoder:
     """Dense decoder passes for either decoder class, on operands in the active precision."""
 
@@ -41,7 +64,16 @@ class _Decoder:
         self.clt = isinstance(dec, CrosslayerDecoder)
         self.L = dec.n_layers
         self.W32 = dec.weights()
-        self.Wop = [_op(w) for w in self.W32]
+        self._Wop = None
+
+    @property
+    def Wop(self):
+        if self._Wop is None:
+            self._Wop = [_op(w) for w in self.W32]
+        return self._Wop
+
+    def names(self):
+        return [f"decoder.W_{l}" for l in range(self.L)] if self.clt else ["decoder.W"]
 
     def fwd(self, fo):
         return ops.clt_decoder_fwd(fo, self.Wop, self.dec.b) if self.clt else ops.plt_decoder_fwd(fo, self.Wop[0], self.dec.b)
@@ -69,10 +101,52 @@ class _Decoder:
         for l, w in enumerate(self.W32):
             ops.rowscale_add(w, dn, sq, grads[f"decoder.W_{l}" if self.clt else "decoder.W"])
 
+    # ---- sparse (list) passes -------------------------------------------------------------------
+    def pointer_table(self):
+        """Device array of the L per-target-layer weight base pointers (cached while storages are stable)."""
+        d, F = self.dec.d_acts, self.dec.d_features
+        ptrs = [w.data_ptr() for w in self.W32] if self.clt else [self.W32[0].data_ptr() + 4 * l * F * d for l in range(self.L)]
+        cached = getattr(self.dec, "_wptr", None)
+        if cached is None or cached[0] != ptrs:
+            cached = (ptrs, torch.tensor(ptrs, dtype=torch.int64).to(self.W32[0].device))
+            self.dec._wptr = cached
+        return cached[1]
 
-def training_step(mod, batch: torch.Tensor, batch_idx: int) -> Dict[str, object]:
+    def sparse_fwd(self, S):
+        return ops.sparse_decoder_fwd(S, self.pointer_table(), self.dec.b, self.dec.d_acts, self.clt)
+
+    def sparse_bwd(self, S, g, S2, g2, grads, fused):
+        """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
+        Returns (dval [S.cap], dval2 [S2.cap] or None)."""
+        dev = g.device
+        slots = self.L if self.clt else 1
+        dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
+        dots2 = torch.empty(slots, S2.cap, dtype=torch.float32, device=dev) if S2 is not None else None
+        second = (S2, S2.csc_val, g2) if S2 is not None else None
+        for l, (name, w) in enumerate(zip(self.names(), self.W32)):
+            kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
+            if fused is not None:
+                kw.update(fused.begin_fused(w))
+            else:
+                grads[name] = kw["grad_out"] = torch.empty_like(w)
+            ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+        dval = ops.sparse_reduce_dots(dots, S, self.clt)
+        dval2 = ops.sparse_reduce_dots(dots2, S2, self.clt) if S2 is not None else None
+        return dval, dval2
+
+
+def _list_capacity(nl, Bn, L, F):
+    """Upper bound on the number of positive entries a TopK-family module leaves."""
+    return max(1, min(nl.k, F) * Bn * L)
+
+
+def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, sparse: Optional[bool] = None) -> Dict[str, object]:
     """Returns {"loss": 0-dim fp32 tensor, "terms": {name: tensor}, "grads": {param_name: tensor},
-    "dead": uint8 [L,F]}.  `mod` is a CrossLayerTranscoderModule (or subclass)."""
+    "dead": uint8 [L,F], ...}.  `mod` is a CrossLayerTranscoderModule (or subclass).
+
+    optimizer: a FusedAdam — in the sparse regime the encoder/decoder weight matrices are then updated in
+    place by the backward row pass and do not appear in "grads" (the optimizer's step() afterwards covers the
+    remaining parameters).  sparse: force (True) / forbid (False) the list regime; default = TopK family."""
     model = mod.model
     enc, dec, nl = model.encoder, model.decoder, model.nonlinearity
     if not batch.is_cuda:
@@ -89,34 +163,81 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int) -> Dict[str, object]
     Bn, L, d = resid.shape
     F = enc.d_features
     bf16 = get_precision() == "bf16"
-    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, not bf16, bf16)
-    xo = xs16 if bf16 else xs32
-    pre = ops.encoder_fwd(xo, _op(enc.W), enc.b)
-
     kind = mod._loss_kind
+    topk_family = isinstance(nl, (PerLayerTopK, BatchTopK, PerLayerBatchTopK))
+    if sparse is None:
+        sparse = topk_family and kind in ("base", "topk")
+    if sparse and not (topk_family and kind in ("base", "topk")):
+        raise NotImplementedError("the sparse regime covers TopK-family sparsifiers with the base / TopK-aux losses")
+
+    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, sparse or not bf16, bf16)
+    xo = xs16 if bf16 else xs32
+    pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
+
     theta = None
     if isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
     elif isinstance(nl, ReLU):
         feat = ops.relu_fwd(pre)
-    elif isinstance(nl, (PerLayerTopK, BatchTopK, PerLayerBatchTopK)):
+    elif topk_family:
         feat = _select(nl, pre)
     else:
         raise NotImplementedError(f"fused step: unsupported nonlinearity {type(nl).__name__}")
 
     D = _Decoder(dec)
-    fo = _op(feat)
-    r = D.fwd(fo)
-    want_ys = kind == "topk"
-    loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
     N = Bn * L * d
-    terms = {"mse": (loss_sum[0] / N).float()}
     grads: Dict[str, torch.Tensor] = {}
+    want_ys = kind == "topk"
 
-    fired = ops.column_any_positive(feat)
+    if sparse:
+        S = ops.sparse_build(feat, _list_capacity(nl, Bn, L, F))
+        r = D.sparse_fwd(S)
+        fired = S.fired
+    else:
+        fo = _op(feat)
+        r = D.fwd(fo)
+        fired = ops.column_any_positive(feat)
+    loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
+    terms = {"mse": (loss_sum[0] / N).float()}
     dead, dead_cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F)
+    out = {"terms": terms, "grads": grads, "dead": dead, "features": feat, "recons_norm": r, "pre_actvs": pre}
+
+    if sparse:
+        S2 = g_aux = None
+        if kind == "topk":
+            aux = mod.topk_aux
+            dead_feat = _select(aux, ops.mask_dead(pre, dead))
+            S2 = ops.sparse_build(dead_feat, _list_capacity(aux, Bn, L, F))
+            aux_r = D.sparse_fwd(S2)
+            aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
+            terms["aux"] = (aux_sum[0] / N).float()
+            loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
+            grads["decoder.b"] = ops.column_sum(g_aux)
+        else:
+            loss = terms["mse"]
+        grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
+        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux, grads, optimizer)
+        # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
+        # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
+        db = torch.empty(L, F, dtype=torch.float32, device=pre.device)
+        Wt = enc.Wt
+        kw = dict(colsum=db, second=(S2, dval2, xs32) if S2 is not None else None)
+        if optimizer is not None:
+            kw.update(optimizer.begin_fused(enc.W, storage=Wt))
+            if bf16:
+                kw["shadow"] = _encoder_operand(enc)
+        else:
+            dWt = torch.empty_like(Wt)
+            kw["grad_out"] = dWt
+            grads["encoder.W"] = dWt.permute(0, 2, 1)
+        ops.sparse_row_pass(Wt, S, dval, xs32, 0, -1, **kw)
+        grads["encoder.b"] = db
+        out["lists"] = S
+        terms["loss"] = loss
+        out["loss"] = loss
+        return out
 
     if kind == "jumprelu":
         if not isinstance(nl, (JumpReLU, ReLU)):
@@ -167,8 +288,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int) -> Dict[str, object]
         if kind == "topk":
             ops.mask_positive(dead_feat, D.dgrad(gao), out=dpre, accumulate=True)   # aux path reaches dead entries only
 
-    grads["encoder.W"] = ops.encoder_wgrad(xo, _op(dpre))
+    grads["encoder.W"] = ops.encoder_wgrad(xo, _op(dpre)).permute(0, 2, 1)
     grads["encoder.b"] = ops.column_sum(dpre)
     terms["loss"] = loss
-    return {"loss": loss, "terms": terms, "grads": grads, "dead": dead, "features": feat, "recons_norm": r,
-            "pre_actvs": pre}
+    out["loss"] = loss
+    return out

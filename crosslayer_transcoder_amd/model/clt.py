@@ -15,6 +15,12 @@ from .serializable_module import SerializableModule
 from .standardize import Standardizer
 
 
+def _feature_major(W: torch.Tensor) -> torch.Tensor:
+    """[L,d,F] encoder weight -> its [L,F,d] storage view (a free permute when the layout is the native one)."""
+    Wt = W.permute(0, 2, 1)
+    return Wt if Wt.is_contiguous() else Wt.contiguous()
+
+
 def _operand(t: torch.Tensor) -> torch.Tensor:
     """fp32 tensor -> GEMM operand in the active precision."""
     from .. import ops
@@ -26,7 +32,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xs, W, b):
         from .. import ops
-        xo, Wo = _operand(xs), _operand(W)
+        xo, Wo = _operand(xs), _operand(_feature_major(W))
         ctx.save_for_backward(xo, Wo)
         ctx.has_bias = b is not None
         return ops.encoder_fwd(xo, Wo, b)
@@ -36,15 +42,9 @@ class _EncoderFn(torch.autograd.Function):
         from .. import ops
         xo, Wo = ctx.saved_tensors
         do = _operand(dpre)
-        dW = ops.encoder_wgrad(xo, do) if ctx.needs_input_grad[1] else None
+        dW = ops.encoder_wgrad(xo, do).permute(0, 2, 1) if ctx.needs_input_grad[1] else None
         db = ops.column_sum(dpre.contiguous()) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        dx = None
-        if ctx.needs_input_grad[0]:          # only when the caller differentiates w.r.t. activations
-            Bn, L, F = dpre.shape
-            d = xo.shape[2]
-            dx = torch.empty(Bn, L, d, dtype=torch.float32, device=dpre.device)
-            ops._gemm(ops._fn_for(do), do, 0, Wo, 0, dx, 0, Bn, d, F, L * F, F, L * d, False, True, batch=L, sA=F,
-                      sB=d * F, sC=d)
+        dx = ops.encoder_dgrad(do, Wo) if ctx.needs_input_grad[0] else None   # only if activations need grad
         return dx, dW, db
 
 
@@ -54,7 +54,10 @@ class Encoder(SerializableModule):
     def __init__(self, d_acts: int, d_features: int, n_layers: int):
         super().__init__()
         self.d_acts, self.d_features, self.n_layers = d_acts, d_features, n_layers
-        self.W = nn.Parameter(torch.empty(n_layers, d_acts, d_features))
+        # Same name and logical shape [L,d,F] as the reference (state-dict compatible), but stored
+        # feature-major ([L,F,d] in memory): one feature's d weights are contiguous, which is what the MFMA
+        # B-operand (k-contiguous) and the sparse per-feature gradient/Adam row pass both want.
+        self.W = nn.Parameter(torch.empty(n_layers, d_features, d_acts).permute(0, 2, 1))
         self.bias = True
         self.b = nn.Parameter(torch.empty(n_layers, d_features))
         self._is_folded = False
@@ -72,8 +75,18 @@ class Encoder(SerializableModule):
         from .. import ops
         shp = acts_norm.shape
         x = _operand(acts_norm.reshape(-1, 1, shp[-1]))
-        W = _operand(self.W[layer:layer + 1])
+        W = _operand(self.Wt[layer:layer + 1])
         return ops.encoder_fwd(x, W, self.b[layer:layer + 1].contiguous()).reshape(*shp[:-1], self.d_features)
+
+    @property
+    def Wt(self) -> torch.Tensor:
+        """Feature-major [L,F,d] view of W (contiguous; re-laid out once if a load/assignment changed it)."""
+        Wt = self.W.permute(0, 2, 1)
+        if not Wt.is_contiguous():
+            with torch.no_grad():
+                self.W.data = Wt.contiguous().permute(0, 2, 1)
+            Wt = self.W.permute(0, 2, 1)
+        return Wt
 
     def forward(self, acts_norm, layer="all"):
         if layer != "all":

@@ -106,10 +106,12 @@ class CrossLayerTranscoderModule(_Base):
         for k, v in terms.items():
             self.log(names.get(k, k), v)
 
-    def compute_step(self, batch, batch_idx):
-        """Loss + gradients through the fused engine (no autograd).  Result kept in `self.last_step`."""
+    def compute_step(self, batch, batch_idx, optimizer=None, sparse=None):
+        """Loss + gradients through the fused engine (no autograd).  Result kept in `self.last_step`.
+        With `optimizer` (a FusedAdam) the sparse regime applies Adam to the weight matrices inside its
+        backward row pass; those parameters are then absent from out["grads"]."""
         with torch.no_grad():
-            out = engine.training_step(self, batch, batch_idx)
+            out = engine.training_step(self, batch, batch_idx, optimizer, sparse)
         self.last_step = out
         self._log_terms(out["terms"])
         return out
@@ -122,9 +124,9 @@ class CrossLayerTranscoderModule(_Base):
         gs = [out["grads"][n].reshape(params[n].shape) for n in names]
         return _StepLoss.apply(out["loss"], self.assume_unit_loss_grad, *ps, *gs)
 
-    def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None):
+    def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None, fuse_adam=True, sparse=None):
         """fwd + bwd + Adam with no autograd bookkeeping: what bench.py times."""
-        out = self.compute_step(batch, batch_idx)
+        out = self.compute_step(batch, batch_idx, optimizer if fuse_adam else None, sparse)
         params = self._named_model_params()
         for n, p in params.items():
             g = out["grads"].get(n)

@@ -14,6 +14,20 @@ from ._lib import call, lib
 
 _ws = {}
 
+#: kernel timing hook (bench.py): when a dict, selected launches are bracketed by HIP events recorded on the
+#: launch stream (= torch's current stream) and appended as name -> [(start, end, payload), ...].  No sync.
+TIMING = None
+
+
+def _timed_call(tag, payload, name, *args):
+    if TIMING is None:
+        return call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(name, *args)
+    e1.record()
+    TIMING.setdefault(tag, []).append((e0, e1, payload))
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -89,35 +103,36 @@ def _fn_for(t):
     return "clt_gemm_bf16" if t.dtype == torch.bfloat16 else "clt_gemm_f32"
 
 
-def encoder_fwd(xs: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """pre[b,l,:] = xs[b,l,:] @ W[l] + b[l]   (clt.py:157-165).  xs/W fp32, or both bf16 (W as [L,d,F])."""
+def encoder_fwd(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """pre[b,l,:] = xs[b,l,:] @ W[l] + b[l]   (clt.py:157-165).  `Wt` is the feature-major storage of the
+    encoder weight, [L,F,d] (= W.permute(0,2,1)), so both operands are k-contiguous; fp32 or bf16."""
     Bn, L, d = xs.shape
-    F = W.shape[2]
-    _chk(xs, xs.dtype); _chk(W, xs.dtype)
+    F = Wt.shape[1]
+    _chk(xs, xs.dtype); _chk(Wt, xs.dtype)
     pre = torch.empty(Bn, L, F, dtype=torch.float32, device=xs.device)
-    _gemm(_fn_for(xs), xs, 0, W, 0, pre, 0, Bn, F, d, L * d, F, L * F, False, False, batch=L, sA=d, sB=d * F, sC=F,
+    _gemm(_fn_for(xs), xs, 0, Wt, 0, pre, 0, Bn, F, d, L * d, d, L * F, False, True, batch=L, sA=d, sB=d * F, sC=F,
           bias=b, sBias=F)
     return pre
 
 
-def encoder_fwd_wt(xs16: torch.Tensor, Wt16: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """bf16 fast form: Wt16 is the transposed shadow [L,F,d] so both operands are k-contiguous."""
-    Bn, L, d = xs16.shape
-    F = Wt16.shape[1]
-    pre = torch.empty(Bn, L, F, dtype=torch.float32, device=xs16.device)
-    _gemm("clt_gemm_bf16", xs16, 0, Wt16, 0, pre, 0, Bn, F, d, L * d, d, L * F, False, True, batch=L, sA=d, sB=d * F,
-          sC=F, bias=b, sBias=F)
-    return pre
-
-
 def encoder_wgrad(xs: torch.Tensor, dpre: torch.Tensor) -> torch.Tensor:
-    """dW[l] = xs[:,l]^T @ dpre[:,l]."""
+    """dWt[l] = dpre[:,l]^T @ xs[:,l]  -> [L,F,d] (feature-major, like the weight storage)."""
     Bn, L, d = xs.shape
     F = dpre.shape[2]
     _chk(xs, xs.dtype); _chk(dpre, xs.dtype)
-    dW = torch.empty(L, d, F, dtype=torch.float32, device=xs.device)
-    _gemm(_fn_for(xs), xs, 0, dpre, 0, dW, 0, d, F, Bn, L * d, L * F, F, True, False, batch=L, sA=d, sB=F, sC=d * F)
-    return dW
+    dWt = torch.empty(L, F, d, dtype=torch.float32, device=xs.device)
+    _gemm(_fn_for(xs), dpre, 0, xs, 0, dWt, 0, F, d, Bn, L * F, L * d, d, True, False, batch=L, sA=F, sB=d, sC=d * F)
+    return dWt
+
+
+def encoder_dgrad(dpre: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
+    """dx[:,l] = dpre[:,l] @ W[l]^T (only when the caller differentiates w.r.t. the activations)."""
+    Bn, L, F = dpre.shape
+    d = Wt.shape[2]
+    dx = torch.empty(Bn, L, d, dtype=torch.float32, device=dpre.device)
+    _gemm(_fn_for(dpre), _chk(dpre, dpre.dtype), 0, _chk(Wt, dpre.dtype), 0, dx, 0, Bn, d, F, L * F, d, L * d, False,
+          False, batch=L, sA=F, sB=d * F, sC=d)
+    return dx
 
 
 def clt_decoder_fwd(feat: torch.Tensor, Ws: List[torch.Tensor], b: Optional[torch.Tensor]) -> torch.Tensor:
@@ -388,8 +403,91 @@ def dead_update(fired, tokens: int, last_active, tokens_till_dead: int):
 # ---------------------------------------------------------------------------------------------- K13
 def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False,
          bf16_shadow=None):
-    for t in (p, g, m, v):
-        _chk(t)
+    for t in (p, g, m, v):                       # any dense layout, as long as all four share it
+        _chk(t, contiguous=False)
+        if t.stride() != p.stride() or t.shape != p.shape:
+            raise ValueError("adam: p, g, m, v must share one memory layout")
+    if not (p.is_contiguous() or p.permute(*sorted(range(p.dim()), key=lambda i: -p.stride(i))).is_contiguous()):
+        raise ValueError("adam: parameter storage must be dense")
     call("clt_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), float(weight_decay), int(adamw), int(step),
          bf16_shadow.data_ptr() if bf16_shadow is not None else None, _stream())
+
+
+# ------------------------------------------------------------------------------ sparse decoder path
+class SparseLists:
+    """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
+    __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
+                 "csc_ent", "fired", "total", "overflow")
+
+
+def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
+    _chk(feat)
+    Bn, L, F = feat.shape
+    dev = feat.device
+    s = SparseLists()
+    s.B, s.L, s.F, s.cap = Bn, L, F, int(cap)
+    i32 = dict(dtype=torch.int32, device=dev)
+    s.row_start = torch.empty(Bn * L + 1, **i32)
+    s.ent_col = torch.empty(cap, **i32)
+    s.ent_val = torch.empty(cap, dtype=torch.float32, device=dev)
+    s.col_start = torch.empty(L * F + 1, **i32)
+    s.csc_tok = torch.empty(cap, **i32)
+    s.csc_val = torch.empty(cap, dtype=torch.float32, device=dev)
+    s.csc_ent = torch.empty(cap, **i32)
+    s.fired = torch.empty(L, F, dtype=torch.uint8, device=dev)
+    s.total = torch.empty(1, **i32)
+    s.overflow = torch.empty(1, **i32)
+    nb = lib.clt_sparse_build_workspace_bytes(Bn, L, F)
+    ws = workspace(nb, dev)
+    call("clt_sparse_build_f32", feat.data_ptr(), Bn, L, F, s.cap, s.row_start.data_ptr(), s.ent_col.data_ptr(),
+         s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(), s.csc_ent.data_ptr(),
+         s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return s
+
+
+def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
+    """Device array of device pointers (one small H2D copy; cache it while the storages are stable)."""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(tensors[0].device)
+
+
+def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool):
+    out = torch.empty(s.B, s.L, d, dtype=torch.float32, device=wptr.device)
+    call("clt_sparse_decoder_fwd_f32", s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(),
+         wptr.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), s.B, s.L, s.F, d,
+         int(cross_layer), s.cap, _stream())
+    return out
+
+
+def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
+                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None):
+    """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
+    weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
+    `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
+    per-entry dots go to `dots2` ([slots, lists2.cap])."""
+    _chk(W); _chk(coef); _chk(src)
+    d = W.shape[-1]
+    rows = W.numel() // d
+    a = adam or dict(lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False, step=1)
+    s2, c2, x2 = second if second is not None else (None, None, None)
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
+         src_layer, s.col_start.data_ptr(), s.csc_tok.data_ptr(), coef.data_ptr(), src.data_ptr(),
+         ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
+         ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
+         float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
+         int(a["step"]), _stream())
+
+
+def sparse_reduce_dots(dots, s: SparseLists, cross_layer: bool):
+    dval = torch.empty(s.cap, dtype=torch.float32, device=dots.device)
+    call("clt_sparse_reduce_dots_f32", dots.data_ptr(), s.cap, s.col_start.data_ptr(), s.L, s.F, int(cross_layer),
+         dval.data_ptr(), _stream())
+    return dval
+
+
+def sparse_scatter_dense(s: SparseLists, val):
+    out = torch.empty(s.B, s.L, s.F, dtype=torch.float32, device=val.device)
+    call("clt_sparse_scatter_dense_f32", s.col_start.data_ptr(), s.csc_tok.data_ptr(), val.data_ptr(), s.B, s.L * s.F,
+         out.data_ptr(), _stream())
+    return out

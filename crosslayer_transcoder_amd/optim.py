@@ -1,14 +1,50 @@
 """Fused Adam / AdamW on the HIP kernel clt_adam_f32 (replaces torch.optim.Adam(fused=True),
 reference model/clt_lightning.py:339-352).  A torch.optim.Optimizer subclass so the reference's
-LinearLR / MultiStepLR schedulers drive it unchanged."""
+LinearLR / MultiStepLR schedulers drive it unchanged.
+
+Parameters may be stored in any dense (non-overlapping) layout — the encoder weight is kept feature-major —
+so the moment buffers are allocated with the parameter's own strides and the kernel walks raw memory."""
 import torch
 
 from . import ops
 
 
+def _same_layout(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    if t.stride() == like.stride() and t.shape == like.shape:
+        return t
+    out = torch.empty_like(like)                 # preserve_format: takes `like`'s strides
+    out.copy_(t)
+    return out
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)          # same strides as p
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        return st
+
+    def _group_of(self, p):
+        for group in self.param_groups:
+            for q in group["params"]:
+                if q is p:
+                    return group
+        raise KeyError("parameter is not managed by this optimizer")
+
+    def begin_fused(self, p, storage=None):
+        """For a kernel that applies the update itself (clt_sparse_row_pass_f32): counts the step and returns
+        the keyword arguments ops.sparse_row_pass needs (`adam` hyper-parameters, moment buffers)."""
+        group = self._group_of(p)
+        st = self._state(p)
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        return dict(adam=dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
+                              adamw=group["adamw"], step=st["step"]), m=st["exp_avg"], v=st["exp_avg_sq"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -21,13 +57,10 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st = self._state(p)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                g = _same_layout(p.grad, p)
                 ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
-                         group["weight_decay"], group["adamw"], getattr(p, "_bf16_shadow", None))
+                         group["weight_decay"], group["adamw"], None)
+                p._clt_version = getattr(p, "_clt_version", 0) + 1      # cached bf16 operand copies re-cast
         return loss

@@ -165,6 +165,48 @@ int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, doubl
                  double beta2, double eps, double weight_decay, int adamw, int step, uint16_t* bf16_shadow,
                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sparse decoder path (K5b/K6 sparse, fused with K13) — replaces the dense bmm's of clt.py:334-343 and
+ * their autograd when the sparsifier leaves few active features (TopK family; JumpReLU at low L0).
+ *
+ * Lists (built from the dense feature tensor feat [B][L][F], entries = positions with feat > 0):
+ *   token-major CSR : row_start[B*L+1]; ent_col[cap] (= l*F+i), ent_val[cap]; rows ordered (b,l), entries by i
+ *   feature-major CSC: col_start[L*F+1]; csc_tok[cap] (token b), csc_val[cap], csc_ent[cap] (CSR position),
+ *                      entries of a column ordered by token
+ *   fired[L*F] = column non-empty;  total[0] = number of entries;  overflow[0] = 1 if total > cap.
+ * ------------------------------------------------------------------------------------------- */
+size_t clt_sparse_build_workspace_bytes(int B, int L, int F);
+int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
+                         float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
+                         uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace, size_t ws_bytes,
+                         void* stream);
+/* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
+ * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
+ * Wptr: DEVICE array of L device pointers. */
+int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val,
+                               const float* const* Wptr, const float* bias, float* out, int B, int L, int F, int d,
+                               int cross_layer, uint32_t cap, void* stream);
+/* One streaming pass over `rows` weight rows W[r][0:d] (row r <-> CSC column col0 + r):
+ *   grad[r,:]  = sum_{p in column} coef[p] * src[tok[p], layer, :]   (+ the same over the optional 2nd list)
+ *   dot_out[slot*dot_stride + p] = src[tok[p], layer, :] . W[r,:]    (pre-update weights; dot_out2: the same for
+ *                                   the 2nd list; slot = dot_slot, or layer - (col/F) when dot_slot < 0)
+ *   colsum_out[col] = sum_p coef[p]
+ *   grad_out != NULL: grad is written there and nothing else is touched; otherwise the Adam/AdamW update
+ *   (same semantics as clt_adam_f32) is applied to W, m, v in place (+ optional bf16 shadow of W).
+ * layer = src_layer, or (col0 + r) / F when src_layer < 0; src tensors are [B][L][d] fp32. */
+int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
+                            int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
+                            const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
+                            const float* coef2, const float* src2, float* dot_out, float* dot_out2, long dot_stride,
+                            long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, int adamw, int step, void* stream);
+/* dval[p] = sum_{s < (cross_layer ? L - col/F : 1)} dots[s*stride + p]  — d(loss)/d(feature) per CSC entry. */
+int clt_sparse_reduce_dots_f32(const float* dots, long stride, const uint32_t* col_start, int L, int F,
+                               int cross_layer, float* dval, void* stream);
+/* out [B][ncols] = 0 except out[tok[p]][col] = val[p] (dense view of CSC-ordered values). */
+int clt_sparse_scatter_dense_f32(const uint32_t* col_start, const int32_t* tok, const float* val, int B, int ncols,
+                                 float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,29 @@ import torch
 
 Tensor = torch.Tensor
 
+# Optional emulation of the build's bf16 mode (bf16 GEMM operands, fp32 accumulate and fp32 results): every
+# dense-contraction operand passes through _q().  None = exact fp32/fp64 restatement of the reference.
+_OPERAND_DTYPE = None
+
+
+class operand_rounding:
+    """with operand_rounding(torch.bfloat16): ...  — round GEMM operands as the bf16 MFMA path does."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _OPERAND_DTYPE
+        self.old, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *a):
+        global _OPERAND_DTYPE
+        _OPERAND_DTYPE = self.old
+
+
+def _q(t: Tensor) -> Tensor:
+    return t if _OPERAND_DTYPE is None else t.to(_OPERAND_DTYPE).to(t.dtype)
+
 
 # --------------------------------------------------------------------------------------------
 # A1  standardizers — model/standardize.py:39-59 (input), :80-108 (output)
@@ -64,14 +87,14 @@ def encoder_fwd(xs: Tensor, W: Tensor, b: Tensor) -> Tensor:
     B, L, d = xs.shape
     pre = torch.empty(B, L, W.shape[2], dtype=xs.dtype)
     for l in range(L):
-        pre[:, l] = xs[:, l] @ W[l] + b[l]
+        pre[:, l] = _q(xs[:, l]) @ _q(W[l]) + b[l]
     return pre
 
 
 def encoder_bwd(xs: Tensor, dpre: Tensor) -> Tuple[Tensor, Tensor]:
     """dW[l] = xs[:,l]^T @ dpre[:,l];  db = sum_b dpre.  (No dx: the batch does not require grad.)"""
     L = xs.shape[1]
-    dW = torch.stack([xs[:, l].T @ dpre[:, l] for l in range(L)])
+    dW = torch.stack([_q(xs[:, l]).T @ _q(dpre[:, l]) for l in range(L)])
     return dW, dpre.sum(dim=0)
 
 
@@ -187,7 +210,7 @@ def crosslayer_decoder_fwd(feat: Tensor, Ws: List[Tensor], b: Tensor) -> Tensor:
     d = b.shape[1]
     r = torch.empty(B, L, d, dtype=feat.dtype)
     for l in range(L):
-        r[:, l] = feat[:, : l + 1].reshape(B, -1) @ Ws[l].reshape(-1, d)
+        r[:, l] = _q(feat[:, : l + 1].reshape(B, -1)) @ _q(Ws[l].reshape(-1, d))
     return r + b
 
 
@@ -199,21 +222,21 @@ def crosslayer_decoder_bwd(feat: Tensor, Ws: List[Tensor], g: Tensor) -> Tuple[T
     for l in range(L):
         dW = torch.empty_like(Ws[l])
         for lp in range(l + 1):
-            dfeat[:, lp] += g[:, l] @ Ws[l][lp].T
-            dW[lp] = feat[:, lp].T @ g[:, l]
+            dfeat[:, lp] += _q(g[:, l]) @ _q(Ws[l][lp]).T
+            dW[lp] = _q(feat[:, lp]).T @ _q(g[:, l])
         dWs.append(dW)
     return dfeat, dWs, g.sum(dim=0)
 
 
 def plt_decoder_fwd(feat: Tensor, W: Tensor, b: Tensor) -> Tensor:
     L = feat.shape[1]
-    return torch.stack([feat[:, l] @ W[l] for l in range(L)], dim=1) + b
+    return torch.stack([_q(feat[:, l]) @ _q(W[l]) for l in range(L)], dim=1) + b
 
 
 def plt_decoder_bwd(feat: Tensor, W: Tensor, g: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     L = feat.shape[1]
-    dfeat = torch.stack([g[:, l] @ W[l].T for l in range(L)], dim=1)
-    dW = torch.stack([feat[:, l].T @ g[:, l] for l in range(L)])
+    dfeat = torch.stack([_q(g[:, l]) @ _q(W[l]).T for l in range(L)], dim=1)
+    dW = torch.stack([_q(feat[:, l]).T @ _q(g[:, l]) for l in range(L)])
     return dfeat, dW, g.sum(dim=0)
 
 

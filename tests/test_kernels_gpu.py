@@ -46,13 +46,16 @@ def test_standardizer(ops, B, L, d):
 @pytest.mark.parametrize("B,L,d,F", [(16, 2, 110, 32), (5, 3, 7, 9), (130, 2, 96, 200), (64, 12, 768, 256)])
 def test_dense_contractions_f32(ops, B, L, d, F):
     xs, W, b = _rand(B, L, d, seed=1), _rand(L, d, F, seed=2, scale=F ** -0.5), _rand(L, F, seed=3, scale=0.1)
-    pre = ops.encoder_fwd(xs.to(DEV), W.to(DEV), b.to(DEV))
+    Wt = W.transpose(1, 2).contiguous()                       # feature-major storage [L,F,d]
+    pre = ops.encoder_fwd(xs.to(DEV), Wt.to(DEV), b.to(DEV))
     ref = O.encoder_fwd(xs.double(), W.double(), b.double())
     assert_close(pre, ref, **tol(ref), what="encoder fwd")
     dpre = _rand(B, L, F, seed=4)
-    dW = ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV))
+    dWt = ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV))
     rW, _ = O.encoder_bwd(xs.double(), dpre.double())
-    assert_close(dW, rW, **tol(rW), what="encoder wgrad")
+    assert_close(dWt.permute(0, 2, 1), rW, **tol(rW), what="encoder wgrad")
+    rdx = torch.stack([dpre[:, l].double() @ W[l].double().T for l in range(L)], 1)
+    assert_close(ops.encoder_dgrad(dpre.to(DEV), Wt.to(DEV)), rdx, **tol(rdx), what="encoder dgrad")
     feat = torch.relu(_rand(B, L, F, seed=5))
     Ws = [_rand(l + 1, F, d, seed=10 + l, scale=0.05) for l in range(L)]
     bd = _rand(L, d, seed=6, scale=0.1)
@@ -90,12 +93,11 @@ def test_dense_contractions_bf16(ops, B, L, d, F):
     xs, W = _rand(B, L, d, seed=1).to(bf), _rand(L, d, F, seed=2, scale=F ** -0.5).to(bf)
     b = _rand(L, F, seed=3, scale=0.1)
     ref = O.encoder_fwd(xs.double(), W.double(), b.double())
-    assert_close(ops.encoder_fwd(xs.to(DEV), W.to(DEV), b.to(DEV)), ref, **tol(ref, 2e-6), what="enc bf16")
     Wt = W.transpose(1, 2).contiguous()
-    assert_close(ops.encoder_fwd_wt(xs.to(DEV), Wt.to(DEV), b.to(DEV)), ref, **tol(ref, 2e-6), what="enc bf16 NT")
+    assert_close(ops.encoder_fwd(xs.to(DEV), Wt.to(DEV), b.to(DEV)), ref, **tol(ref, 2e-6), what="enc bf16 NT")
     dpre = _rand(B, L, F, seed=4).to(bf)
     rW, _ = O.encoder_bwd(xs.double(), dpre.double())
-    assert_close(ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV)), rW, **tol(rW, 2e-6), what="enc wgrad bf16")
+    assert_close(ops.encoder_wgrad(xs.to(DEV), dpre.to(DEV)).permute(0, 2, 1), rW, **tol(rW, 2e-6), what="enc wgrad bf16")
     feat = torch.relu(_rand(B, L, F, seed=5)).to(bf)
     Ws = [_rand(l + 1, F, d, seed=10 + l, scale=0.05).to(bf) for l in range(L)]
     g = _rand(B, L, d, seed=7).to(bf)
@@ -275,3 +277,108 @@ def test_adam(ops):
             pr, mr, vr = O.adam_step(pr, gs, mr, vr, step, 1e-3, 0.9, 0.999, 1e-8, wd, adamw)
         assert_close(pd, pr, 1e-6, 1e-7, "p"); assert_close(m, mr, 1e-5, 1e-9, "m"); assert_close(v, vr, 1e-5, 1e-12, "v")
         assert torch.equal(sh.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------ sparse (list) path
+def _sparse_features(B, L, F, k, seed):
+    pre = _rand(B, L, F, seed=seed)
+    feat, _ = O.per_layer_topk_fwd(pre, k)
+    return feat
+
+
+@pytest.mark.parametrize("B,L,F,d,k", [(16, 2, 32, 110, 4), (33, 3, 100, 20, 7), (8, 12, 512, 768, 16), (5, 2, 40, 7, 40)])
+def test_sparse_lists_and_decoder(ops, B, L, F, d, k):
+    """CSR/CSC construction is exact; gather forward and the fused row pass (dW, dots, Adam) match the dense
+    oracle formulas."""
+    feat = _sparse_features(B, L, F, k, seed=B + F)
+    if k == F:
+        feat[0] = 0                                           # an empty token row
+    fd = feat.to(DEV)
+    cap = k * B * L
+    S = ops.sparse_build(fd, cap)
+    nz = feat.reshape(B * L, F) > 0
+    n = int(nz.sum())
+    assert int(S.total) == n and int(S.overflow) == 0
+    cnt = nz.sum(1)
+    assert torch.equal(S.row_start.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+    rows, cols = nz.nonzero(as_tuple=True)                     # row-major order == CSR order
+    layer = rows % L
+    assert torch.equal(S.ent_col.cpu()[:n].long(), layer * F + cols)
+    assert torch.equal(S.ent_val.cpu()[:n], feat.reshape(B * L, F)[nz])
+    colmat = feat.permute(1, 2, 0).reshape(L * F, B) > 0       # [column, token]
+    assert torch.equal(S.col_start.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), colmat.sum(1).cumsum(0)]))
+    cc, tt = colmat.nonzero(as_tuple=True)
+    assert torch.equal(S.csc_tok.cpu()[:n].long(), tt)
+    assert torch.equal(S.csc_val.cpu()[:n], feat.permute(1, 2, 0).reshape(L * F, B)[colmat])
+    assert torch.equal(S.fired.cpu().bool().reshape(-1), colmat.any(1))
+    assert torch.equal(S.ent_val.cpu()[S.csc_ent.cpu()[:n].long()], S.csc_val.cpu()[:n])
+    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), feat)
+    # overflow is flagged, not fatal
+    if n > 1:
+        assert int(ops.sparse_build(fd, n - 1).overflow) == 1
+
+    g = _rand(B, L, d, seed=7)
+    gd = g.to(DEV)
+    bias = _rand(L, d, seed=8, scale=0.1)
+    for cross in (True, False):
+        if cross:
+            Ws = [_rand(l + 1, F, d, seed=10 + l, scale=0.05) for l in range(L)]
+            Wd = [w.to(DEV) for w in Ws]
+            wptr = ops.pointer_table(Wd)
+            ref = O.crosslayer_decoder_fwd(feat.double(), [w.double() for w in Ws], bias.double())
+            rdf, rdW, _ = O.crosslayer_decoder_bwd(feat.double(), [w.double() for w in Ws], g.double())
+        else:
+            Wp = _rand(L, F, d, seed=9, scale=0.05)
+            Ws, Wd = [Wp], [Wp.to(DEV)]
+            wptr = ops.pointer_table([Wd[0][l] for l in range(L)])
+            ref = O.plt_decoder_fwd(feat.double(), Wp.double(), bias.double())
+            rdf, rdWp, _ = O.plt_decoder_bwd(feat.double(), Wp.double(), g.double())
+            rdW = [rdWp]
+        out = ops.sparse_decoder_fwd(S, wptr, bias.to(DEV), d, cross)
+        assert_close(out, ref, **tol(ref), what=f"sparse fwd cross={cross}")
+        slots = L if cross else 1
+        dots = torch.zeros(slots, cap, device=DEV)
+        for l, w in enumerate(Wd):
+            dW = torch.empty_like(w)
+            ops.sparse_row_pass(w, S, S.csc_val, gd, 0, l if cross else -1, grad_out=dW, dots=dots,
+                                dot_slot=-1 if cross else 0)
+            assert_close(dW, rdW[l], **tol(rdW[l]), what=f"sparse wgrad {l} cross={cross}")
+        dval = ops.sparse_reduce_dots(dots, S, cross)
+        dfeat = ops.sparse_scatter_dense(S, dval).cpu()
+        want = (rdf * (feat > 0)).float()
+        assert_close(dfeat, want, **tol(want), what=f"sparse dfeat cross={cross}")
+        # fused Adam == gradient + clt_adam_f32 (same per-element arithmetic up to FMA contraction)
+        w = Wd[-1]
+        wa, wb = w.clone(), w.clone()
+        m1, v1 = torch.rand_like(w) * 1e-3, torch.rand_like(w) * 1e-6
+        m2, v2 = m1.clone(), v1.clone()
+        hp = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, adamw=True, step=3)
+        sh = torch.empty(w.shape, dtype=torch.bfloat16, device=DEV)
+        ops.sparse_row_pass(wa, S, S.csc_val, gd, 0, (len(Wd) - 1) if cross else -1, adam=hp, m=m1, v=v1, shadow=sh)
+        dW = torch.empty_like(w)
+        ops.sparse_row_pass(wb, S, S.csc_val, gd, 0, (len(Wd) - 1) if cross else -1, grad_out=dW)
+        ops.adam(wb, dW, m2, v2, 3, 1e-3, 0.9, 0.999, 1e-8, 0.01, True)
+        assert_close(wa, wb, 1e-6, 1e-8, "fused adam p"); assert_close(m1, m2, 1e-6, 1e-10, "m"); assert_close(v1, v2, 1e-6, 1e-13, "v")
+        assert torch.equal(sh.cpu(), wa.cpu().to(torch.bfloat16))
+
+
+def test_sparse_row_pass_two_lists_and_encoder(ops):
+    """Second (aux) list, per-column coefficient sums and the layer-from-column addressing used by the encoder."""
+    B, L, F, d = 21, 3, 64, 24
+    f1, f2 = _sparse_features(B, L, F, 5, seed=1), _sparse_features(B, L, F, 9, seed=2)
+    S1, S2 = ops.sparse_build(f1.to(DEV), 5 * B * L), ops.sparse_build(f2.to(DEV), 9 * B * L)
+    xs = _rand(B, L, d, seed=3)
+    c1, c2 = _rand(S1.cap, seed=4).to(DEV), _rand(S2.cap, seed=5).to(DEV)
+    dp1, dp2 = ops.sparse_scatter_dense(S1, c1).cpu().double(), ops.sparse_scatter_dense(S2, c2).cpu().double()
+    Wt = _rand(L, F, d, seed=6).to(DEV)
+    dWt = torch.empty_like(Wt)
+    db = torch.empty(L, F, device=DEV)
+    dots2 = torch.zeros(1, S2.cap, device=DEV)
+    ops.sparse_row_pass(Wt, S1, c1, xs.to(DEV), 0, -1, grad_out=dWt, colsum=db, second=(S2, c2, xs.to(DEV)), dots2=dots2)
+    dpre = dp1 + dp2
+    rW, rb = O.encoder_bwd(xs.double(), dpre)
+    assert_close(dWt.permute(0, 2, 1), rW, **tol(rW), what="encoder wgrad from lists")
+    assert_close(db, rb, **tol(rb), what="encoder db from lists")
+    want = torch.stack([xs[:, l].double() @ Wt[l].cpu().double().T for l in range(L)], 1) * (f2 > 0)
+    got = ops.sparse_scatter_dense(S2, ops.sparse_reduce_dots(dots2, S2, False)).cpu()
+    assert_close(got, want.float(), **tol(want), what="dots of the 2nd list")
