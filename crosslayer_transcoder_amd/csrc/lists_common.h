@@ -1,0 +1,173 @@
+// List-construction kernels shared by sparse.hip (lists from a dense feature tensor) and select_lists.hip
+// (lists straight from the selection).  Every kernel takes a trailing `gate`: NULL = always run, otherwise the
+// kernel runs only when (*gate != 0) == gate_on (device-side choice between the fast path and the exact fallback).
+#pragma once
+#include "common.h"
+
+namespace {
+constexpr int LTPB = 256;
+// ------------------------------------------------------------------------------------------------
+// list construction
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restrict__ feat, int F, uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ uint32_t sh[4];
+    const float* xr = feat + (long)blockIdx.x * F;
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < F; i += LTPB) c += xr[i] > 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ start,
+                                                     uint32_t* __restrict__ total, uint8_t* __restrict__ fired, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ uint32_t sh[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? cnt[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t s = sh[k]; if (k < w) wbase += s; tot += s; }
+        const uint32_t c0 = carry;
+        if (i < n) { start[i] = c0 + wbase + inc - v; if (fired) fired[i] = v > 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c0 + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { start[n] = carry; if (total) *total = carry; }
+}
+
+// ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row
+__global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L,
+                                                        const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
+                                                        float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ uint32_t wcnt[4];
+    const long row = blockIdx.x;
+    const float* xr = feat + row * F;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = ((F + 3) / 4 + 63) / 64 * 64;
+    const int s0 = w * seg, s1 = min(F, s0 + seg);
+    uint32_t c = 0;
+    for (int i = s0 + lane; i < s1; i += 64) c += xr[i] > 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) wcnt[w] = c;
+    __syncthreads();
+    uint32_t off = row_start[row];
+    for (int k = 0; k < w; ++k) off += wcnt[k];
+    const int colbase = (int)(row % L) * F;
+    for (int base = s0; base < s1; base += 64) {
+        const int i = base + lane;
+        const float v = i < s1 ? xr[i] : 0.0f;
+        const bool p = v > 0.0f;
+        const unsigned long long m = __ballot(p);
+        if (p) {
+            const uint32_t pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) { ent_col[pos] = colbase + i; ent_val[pos] = v; }
+            else *overflow = 1;
+        }
+        off += __popcll(m);
+    }
+}
+
+__global__ void count_cols_kernel(const int32_t* __restrict__ ent_col, const uint32_t* __restrict__ total, uint32_t cap,
+                                  uint32_t* __restrict__ col_cnt, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    const uint32_t n = min(*total, cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x)
+        atomicAdd(&col_cnt[ent_col[e]], 1u);
+}
+
+// one wave per CSR row: scatter its entries into the CSC lists (order inside a column fixed up by sort)
+__global__ __launch_bounds__(LTPB) void fill_cols_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
+                                                        const float* __restrict__ ent_val, int rows, int L, uint32_t cap,
+                                                        const uint32_t* __restrict__ col_start, uint32_t* __restrict__ cursor,
+                                                        int32_t* __restrict__ csc_tok, float* __restrict__ csc_val,
+                                                        int32_t* __restrict__ csc_ent, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t e0 = row_start[row], e1 = min(row_start[row + 1], cap);
+    const int tok = row / L;
+    for (uint32_t e = e0 + (threadIdx.x & 63); e < e1; e += 64) {
+        const int c = ent_col[e];
+        const uint32_t pos = col_start[c] + atomicAdd(&cursor[c], 1u);
+        csc_tok[pos] = tok; csc_val[pos] = ent_val[e]; csc_ent[pos] = (int32_t)e;
+    }
+}
+
+// order each column's entries by token.  Short columns: one thread, insertion sort.  Long columns are
+// queued and sorted by a block (bitonic in LDS) in sort_long_cols_kernel.
+constexpr int SHORT_COL = 24, LONGCOL_MAX = 4096;
+__global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int ncols, int32_t* __restrict__ tok,
+                                 float* __restrict__ val, int32_t* __restrict__ ent, int32_t* __restrict__ long_list,
+                                 uint32_t* __restrict__ long_count, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+    if (n < 2) return;
+    if (n > SHORT_COL) { long_list[atomicAdd(long_count, 1u)] = c; return; }
+    for (uint32_t i = 1; i < n; ++i) {
+        const int32_t t = tok[s + i], en = ent ? ent[s + i] : 0; const float v = val[s + i];
+        uint32_t j = i;
+        while (j > 0 && tok[s + j - 1] > t) { tok[s + j] = tok[s + j - 1]; val[s + j] = val[s + j - 1]; if (ent) ent[s + j] = ent[s + j - 1]; --j; }
+        tok[s + j] = t; val[s + j] = v; if (ent) ent[s + j] = en;
+    }
+}
+
+__global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __restrict__ col_start, int32_t* __restrict__ tok,
+                                                             float* __restrict__ val, int32_t* __restrict__ ent,
+                                                             const int32_t* __restrict__ long_list,
+                                                             const uint32_t* __restrict__ long_count, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ unsigned long long key[LONGCOL_MAX];     // (token << 32) | position within the column
+    __shared__ float sval[LONGCOL_MAX];
+    __shared__ int32_t sent[LONGCOL_MAX];
+    const uint32_t nl = *long_count;
+    for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
+        const int c = long_list[q];
+        const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+        if (n > LONGCOL_MAX) continue;                  // left in arrival order (still correct, not bit-reproducible)
+        uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+        for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
+            key[i] = i < n ? (((unsigned long long)(uint32_t)tok[s + i] << 32) | i) : ~0ull;
+            if (i < n) { sval[i] = val[s + i]; sent[i] = ent ? ent[s + i] : 0; }
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= np2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const bool up = (i & k) == 0;
+                        const unsigned long long a = key[i], b = key[ixj];
+                        if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += LTPB) {
+            const uint32_t src = (uint32_t)(key[i] & 0xffffffffu);
+            tok[s + i] = (int32_t)(key[i] >> 32); val[s + i] = sval[src]; if (ent) ent[s + i] = sent[src];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace

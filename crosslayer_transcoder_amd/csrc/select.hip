@@ -6,56 +6,17 @@
 // and LDS histograms; everything > T is selected, and of the entries == T the lowest-index ones fill
 // the remaining slots (canonical tie rule of the build).  Entries whose value is <= 0
 // contribute relu(v) = 0, so ties at T <= 0 never change the output and are not ranked.
-#include "common.h"
+#include "select_common.h"
 
 namespace {
-constexpr int TPB = 256, NBIN = 2048;
-constexpr int SHIFT[3] = {21, 10, 0};
-constexpr int BITS[3] = {11, 11, 10};
-
-struct SegState { uint32_t prefix, mask, krem, eq_total; };
-
-// Exclusive prefix sum of v over the 256 threads of the block (thread order); *total = block sum.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sh /*>=5*/, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    __syncthreads();                       // protect sh from the previous call's readers
-    if (lane == 63) sh[w] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const uint32_t s = sh[i]; if (i < w) base += s; tot += s; }
-    *total = tot;
-    return base + inc - v;
-}
-
-// Given hist[NBIN] in LDS (only the low `nb` bins used) find, scanning from the TOP bin, the bin that
-// holds the krem-th largest matching element.  Results broadcast through res[0..2] (LDS).
-__device__ __forceinline__ void find_bin(const uint32_t* hist, int nb, uint32_t krem, uint32_t* sh, uint32_t* res) {
-    const int per = nb / TPB;                       // 8 or 4 bins per thread
-    const int chunk = TPB - 1 - threadIdx.x;        // thread 0 owns the top bins
-    uint32_t mine = 0;
-    for (int b = 0; b < per; ++b) mine += hist[chunk * per + b];
-    uint32_t tot;
-    uint32_t cum = block_excl_scan(mine, sh, &tot); // elements in strictly higher chunks
-    if (cum < krem && krem <= cum + mine) {
-        for (int b = per - 1; b >= 0; --b) {
-            const uint32_t h = hist[chunk * per + b];
-            if (krem <= cum + h) { res[0] = chunk * per + b; res[1] = krem - cum; res[2] = h; break; }
-            cum += h;
-        }
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------
 // mode 0: k of F per row, one block per row
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXK_COMPACT = 2048;
 __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
-                                                        int32_t* __restrict__ idx_out, float* __restrict__ val_out) {
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                        const uint8_t* __restrict__ col_mask, int L,
+                                                        uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt) {
     __shared__ uint32_t hist[NBIN];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t res[4];
@@ -63,6 +24,9 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
     __shared__ float cval[MAXK_COMPACT];
     const long row = blockIdx.x;
     const float* xr = x + row * F;
+    // optional column mask (where(dead, x, -inf) of clt_lightning.py:544-545 applied on the fly)
+    const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+    auto ld = [&](int i) { return (mk && !mk[i]) ? -INFINITY : xr[i]; };
     uint32_t prefix = 0, mask = 0, krem = k, eq_total = 0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -70,7 +34,7 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
         for (int i = threadIdx.x; i < NBIN; i += TPB) hist[i] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < F; i += TPB) {
-            const uint32_t key = f32_key(xr[i]);
+            const uint32_t key = f32_key(ld(i));
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> SHIFT[p]) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -90,7 +54,7 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
     for (int base = 0; base < F; base += TPB) {
         const int i = base + threadIdx.x;
         float v = 0.0f; uint32_t key = 0;
-        if (i < F) { v = xr[i]; key = f32_key(v); }
+        if (i < F) { v = ld(i); key = f32_key(v); }
         bool sel = (i < F) && key > T;
         const bool eq = (i < F) && key == T;
         if (rank_ties) {
@@ -101,11 +65,15 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
         } else sel |= eq;
         const float o = (sel && v > 0.0f) ? v : 0.0f;
         if (i < F && fr) fr[i] = o;
-        if (idx_out && o > 0.0f) { const uint32_t s = atomicAdd(&res[3], 1u); cidx[s] = i; cval[s] = o; }
+        if (idx_out && o > 0.0f) {
+            const uint32_t s = atomicAdd(&res[3], 1u); cidx[s] = i; cval[s] = o;
+            if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + i], 1u);
+        }
     }
     if (idx_out) {                          // order the <= k positive entries by feature index (rank sort)
         __syncthreads();
         const int n = (int)res[3];
+        if (row_cnt && threadIdx.x == 0) row_cnt[row] = n;
         for (int e = threadIdx.x; e < k; e += TPB) {
             if (e < n) {
                 const int me = cidx[e];
@@ -124,7 +92,8 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
 __device__ __forceinline__ long seg_row(int q, int s, int S, int L) { return S == 1 ? (long)q : (long)q * L + s; }
 
 __global__ __launch_bounds__(TPB) void seg_hist_kernel(const float* __restrict__ x, int F, int L, int S, int RS, int rpb,
-                                                       const SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p) {
+                                                       const SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     __shared__ uint32_t hist[NBIN];
     const int s = blockIdx.y, nb = 1 << BITS[p];
     const uint32_t prefix = state[s].prefix, mask = state[s].mask;
@@ -142,28 +111,9 @@ __global__ __launch_bounds__(TPB) void seg_hist_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < nb; i += TPB) { const uint32_t h = hist[i]; if (h) atomicAdd(&ghist[(long)s * NBIN + i], h); }
 }
 
-__global__ __launch_bounds__(TPB) void seg_find_kernel(SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p) {
-    __shared__ uint32_t hist[NBIN];
-    __shared__ uint32_t sh[8];
-    __shared__ uint32_t res[4];
-    const int s = blockIdx.x, nb = 1 << BITS[p];
-    for (int i = threadIdx.x; i < NBIN; i += TPB) { hist[i] = ghist[(long)s * NBIN + i]; ghist[(long)s * NBIN + i] = 0; }
-    __syncthreads();
-    find_bin(hist, nb, state[s].krem, sh, res);
-    if (threadIdx.x == 0) {
-        SegState st = state[s];
-        st.prefix |= res[0] << SHIFT[p];
-        st.mask |= (uint32_t)(nb - 1) << SHIFT[p];
-        st.krem = res[1];
-        st.eq_total = res[2];
-        state[s] = st;
-    }
-}
-
-__device__ __forceinline__ bool need_rank(const SegState& st) { return st.eq_total != st.krem && key_f32(st.prefix) > 0.0f; }
-
 __global__ __launch_bounds__(TPB) void seg_count_eq_kernel(const float* __restrict__ x, int F, int L, int S, int RS, int rpb,
-                                                           const SegState* __restrict__ state, uint32_t* __restrict__ eqcnt, int NC) {
+                                                           const SegState* __restrict__ state, uint32_t* __restrict__ eqcnt, int NC, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     __shared__ uint32_t sh[8];
     const int s = blockIdx.y;
     const SegState st = state[s];
@@ -181,7 +131,8 @@ __global__ __launch_bounds__(TPB) void seg_count_eq_kernel(const float* __restri
 
 // one block per segment: exclusive scan of the per-chunk tie counts (only if ranking is needed) + EMA
 __global__ void seg_scan_kernel(const SegState* __restrict__ state, uint32_t* __restrict__ eqcnt, int NC,
-                                float* __restrict__ threshold, float e) {
+                                float* __restrict__ threshold, float e, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int s = blockIdx.x;
     if (threadIdx.x != 0) return;
     const SegState st = state[s];
@@ -197,7 +148,8 @@ __global__ void seg_scan_kernel(const SegState* __restrict__ state, uint32_t* __
 
 __global__ __launch_bounds__(TPB) void seg_emit_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int L, int S,
                                                        int RS, int rpb, const SegState* __restrict__ state,
-                                                       const uint32_t* __restrict__ eqoff, int NC) {
+                                                       const uint32_t* __restrict__ eqoff, int NC, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     __shared__ uint32_t sh[8];
     const int s = blockIdx.y;
     const SegState st = state[s];
@@ -224,7 +176,8 @@ __global__ __launch_bounds__(TPB) void seg_emit_kernel(const float* __restrict__
     }
 }
 
-__global__ void seg_init_kernel(SegState* state, int S, uint32_t K) {
+__global__ void seg_init_kernel(SegState* state, int S, uint32_t K, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) { SegState st; st.prefix = 0; st.mask = 0; st.krem = K; st.eq_total = 0; state[s] = st; }
 }
@@ -244,34 +197,31 @@ SegPlan plan(int B, int L, int F, int per_layer) {
 }
 }  // namespace
 
-extern "C" {
-int clt_topk_rows_f32(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out, void* st) {
-    if (rows <= 0 || F <= 0 || k < 0) return CLT_ERR_SHAPE;
+int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
+                           const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st) {
+    if (rows <= 0 || F <= 0 || k < 0 || L <= 0) return CLT_ERR_SHAPE;
     if (k > F) return CLT_ERR_K_GT_F;
     if ((idx_out != nullptr) != (val_out != nullptr)) return CLT_ERR_SHAPE;
     if (idx_out && k > MAXK_COMPACT) return CLT_ERR_RANGE;
     if (!feat && !idx_out) return CLT_ERR_SHAPE;
     if (k == 0) {
-        if (feat && hipMemsetAsync(feat, 0, (size_t)rows * F * sizeof(float), as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (feat && hipMemsetAsync(feat, 0, (size_t)rows * F * sizeof(float), st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (row_cnt && hipMemsetAsync(row_cnt, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         return CLT_OK;
     }
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, as_stream(st), x, feat, F, k, idx_out, val_out);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt,
+                       col_cnt);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
-size_t clt_topk_segmented_workspace_bytes(int B, int L, int F, int per_layer) {
-    if (B <= 0 || L <= 0 || F <= 0) return 0;
-    return plan(B, L, F, per_layer).total;
-}
-
-int clt_topk_segmented_f32(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
-                           float e, void* ws, size_t wsb, void* stp) {
+int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
+                                float e, void* ws, size_t wsb, hipStream_t st, const int32_t* gate) {
     if (B <= 0 || L <= 0 || F <= 0 || k < 0) return CLT_ERR_SHAPE;
     if (k > F) return CLT_ERR_K_GT_F;
     const unsigned long long total = (unsigned long long)B * L * F;
     if (total >= 0xffffffffull) return CLT_ERR_RANGE;
-    hipStream_t st = as_stream(stp);
     if (k == 0) {                                        // topk.py:86-87, 119-122: zeros, no threshold update
+        if (gate) return CLT_ERR_SHAPE;                  // (the gated caller handles k == 0 itself)
         if (hipMemsetAsync(feat, 0, total * sizeof(float), st) != hipSuccess) return CLT_ERR_LAUNCH;
         return CLT_OK;
     }
@@ -282,15 +232,30 @@ int clt_topk_segmented_f32(const float* x, float* feat, int B, int L, int F, int
     uint32_t* eqcnt = (uint32_t*)((char*)ws + p.off_eq);
     const uint32_t K = (uint32_t)((unsigned long long)k * B * (per_layer ? 1 : L));
     if (hipMemsetAsync(ghist, 0, (size_t)p.S * NBIN * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(seg_init_kernel, dim3((p.S + 63) / 64), dim3(64), 0, st, state, p.S, K);
+    hipLaunchKernelGGL(seg_init_kernel, dim3((p.S + 63) / 64), dim3(64), 0, st, state, p.S, K, gate);
     const dim3 grid(p.NC, p.S);
     for (int pass = 0; pass < 3; ++pass) {
-        hipLaunchKernelGGL(seg_hist_kernel, grid, dim3(TPB), 0, st, x, F, L, p.S, p.RS, p.rpb, state, ghist, pass);
-        hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, pass);
+        hipLaunchKernelGGL(seg_hist_kernel, grid, dim3(TPB), 0, st, x, F, L, p.S, p.RS, p.rpb, state, ghist, pass, gate);
+        hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, pass, gate, 1);
     }
-    hipLaunchKernelGGL(seg_count_eq_kernel, grid, dim3(TPB), 0, st, x, F, L, p.S, p.RS, p.rpb, state, eqcnt, p.NC);
-    hipLaunchKernelGGL(seg_scan_kernel, dim3(p.S), dim3(64), 0, st, state, eqcnt, p.NC, threshold, e);
-    hipLaunchKernelGGL(seg_emit_kernel, grid, dim3(TPB), 0, st, x, feat, F, L, p.S, p.RS, p.rpb, state, eqcnt, p.NC);
+    hipLaunchKernelGGL(seg_count_eq_kernel, grid, dim3(TPB), 0, st, x, F, L, p.S, p.RS, p.rpb, state, eqcnt, p.NC, gate);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(p.S), dim3(64), 0, st, state, eqcnt, p.NC, threshold, e, gate);
+    hipLaunchKernelGGL(seg_emit_kernel, grid, dim3(TPB), 0, st, x, feat, F, L, p.S, p.RS, p.rpb, state, eqcnt, p.NC, gate);
     CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+extern "C" {
+int clt_topk_rows_f32(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out, void* st) {
+    return clt_internal_topk_rows(x, feat, rows, F, k, idx_out, val_out, nullptr, 1, nullptr, nullptr, as_stream(st));
+}
+
+size_t clt_topk_segmented_workspace_bytes(int B, int L, int F, int per_layer) {
+    if (B <= 0 || L <= 0 || F <= 0) return 0;
+    return plan(B, L, F, per_layer).total;
+}
+
+int clt_topk_segmented_f32(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
+                           float e, void* ws, size_t wsb, void* stp) {
+    return clt_internal_topk_segmented(x, feat, B, L, F, k, per_layer, threshold, e, ws, wsb, as_stream(stp), nullptr);
 }
 }  // extern "C"

@@ -1,0 +1,457 @@
+// TopK / BatchTopK / PerLayerBatchTopK selection that emits the ACTIVE-ENTRY LISTS directly (gfx950).
+//
+// Replaces torch.topk + relu + scatter_ of the reference (model/topk.py:58-61, 84-91, 117-128) for the sparse
+// regime of the training step: the dense feature tensor [B,L,F] (6.4 GB at the GPT-2 32k shape) is never written
+// or re-read; the kernels read the pre-activations ONCE and produce the token-major CSR and feature-major CSC
+// lists that the gather decoder and the backward row pass consume (same list contract as clt_sparse_build_f32).
+//
+// Batch modes (global / per-layer k*B): the exact k-th largest value is found in two stages
+//   1. a pseudo-random sample of <= 131072 elements per segment gives a lower bound lb that is below the k-th
+//      value with overwhelming probability and leaves ~2-3x K candidates;
+//   2. ONE streaming pass (16-byte loads, per-wave LDS staging, one atomic per flush) compacts every element
+//      >= lb into a candidate list; the exact radix select (11+11+10 bits, select_common.h), the lowest-index tie
+//      rule and the list emission then run on the candidates only.
+// The result is exact whenever count(>= lb) >= K and the candidate / tie buffers do not overflow; otherwise a
+// device-side gate switches — without any host synchronisation — to the exhaustive path (dense radix select +
+// clt_sparse_build), whose kernels are always enqueued and return immediately when the gate is clear.
+// Rows mode (k of F per token row): the one-block-per-row radix select writes its compact (index, value) rows,
+// which are then packed into the CSR.
+#include <math.h>
+#include "select_common.h"
+#include "lists_common.h"
+
+namespace {
+constexpr uint32_t NS_MAX = 131072, TIECAP = 4096;
+constexpr int STG = 512;                      // per-wave candidate staging entries in LDS
+
+struct SelCtl { uint32_t lb, cand_cnt, tie_cnt, pad; };
+struct Head { int32_t gate; uint32_t sel_cnt, long_rows, long_cols; uint32_t pad[60]; };   // 256 B, zeroed per call
+
+__device__ __forceinline__ long lseg_row(int q, int s, int S, int L) { return S == 1 ? (long)q : (long)q * L + s; }
+
+// ---- stage 0: lower bound from a sample -----------------------------------------------------------
+__global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, int F, int L,
+                                                     int S, int RS, uint32_t ns, uint32_t rank, uint32_t Kseg,
+                                                     uint32_t* __restrict__ sample, SegState* __restrict__ state,
+                                                     SelCtl* __restrict__ ctl) {
+    __shared__ uint32_t hist[NBIN];
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t res[4];
+    const int s = blockIdx.x;
+    const unsigned long long nseg = (unsigned long long)RS * F;
+    uint32_t* smp = sample + (size_t)s * ns;
+    if (threadIdx.x == 0) { SegState st; st.prefix = 0; st.mask = 0; st.krem = Kseg; st.eq_total = 0; state[s] = st; }
+    if (rank >= ns) {                          // tiny problem: every element is a candidate
+        if (threadIdx.x == 0) ctl[s].lb = 0u;
+        return;
+    }
+    for (uint32_t j = threadIdx.x; j < ns; j += TPB) {
+        const unsigned long long e = (ns == nseg) ? j : ((((unsigned long long)j + 1) * 0x9E3779B97F4A7C15ull) >> 20) % nseg;
+        const int q = (int)(e / F), i = (int)(e % F);
+        const long row = lseg_row(q, s, S, L);
+        float v = x[row * F + i];
+        if (col_mask && !col_mask[(row % L) * F + i]) v = -INFINITY;
+        smp[j] = f32_key(v);
+    }
+    __syncthreads();
+    uint32_t prefix = 0, mask = 0, krem = rank;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int nb = 1 << BITS[p];
+        for (int i = threadIdx.x; i < NBIN; i += TPB) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < ns; j += TPB) {
+            const uint32_t key = smp[j];
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> SHIFT[p]) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        find_bin(hist, nb, krem, sh, res);
+        prefix |= res[0] << SHIFT[p];
+        mask |= (uint32_t)(nb - 1) << SHIFT[p];
+        krem = res[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ctl[s].lb = prefix;
+}
+
+// ---- stage 1: one streaming pass, candidates >= lb -------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(TPB) void filter_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, int F, int L,
+                                                     int S, int RS, int rpb, SelCtl* __restrict__ ctl, uint32_t capS,
+                                                     uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_idx) {
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ uint32_t skey[4][STG];
+    __shared__ uint32_t sidx[4][STG];
+    const int s = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t lb = ctl[s].lb;
+    uint32_t* ck = cand_key + (size_t)s * capS;
+    uint32_t* ci = cand_idx + (size_t)s * capS;
+    uint32_t scnt = 0;                          // wave-uniform
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto flush = [&]() {
+        if (scnt == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl[s].cand_cnt, scnt);
+        base = __shfl(base, 0, 64);
+        for (uint32_t i = lane; i < scnt; i += 64) {
+            const uint32_t pos = base + i;
+            if (pos < capS) { ck[pos] = skey[w][i]; ci[pos] = sidx[w][i]; }
+        }
+        scnt = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int q0 = blockIdx.x * rpb, q1 = min(RS, q0 + rpb);
+    for (int q = q0 + w; q < q1; q += 4) {
+        const long row = lseg_row(q, s, S, L);
+        const float* xr = x + row * F;
+        const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+        const uint32_t flat0 = (uint32_t)(row * F);
+        for (int base = 0; base < F; base += 64 * W) {
+            const int i0 = base + lane * W;
+            float v[W];
+            if (VEC) {
+                if (i0 < F) { const float4 t = *reinterpret_cast<const float4*>(xr + i0); v[0] = t.x; v[1 % W] = t.y; v[2 % W] = t.z; v[3 % W] = t.w; }
+                else { v[0] = v[1 % W] = v[2 % W] = v[3 % W] = 0.0f; }
+            } else v[0] = i0 < F ? xr[i0] : 0.0f;
+            uint32_t key[W]; bool pr[W];
+            unsigned long long bm[W];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                const int i = i0 + c;
+                float vv = v[c];
+                if (mk && i < F && !mk[i]) vv = -INFINITY;
+                key[c] = f32_key(vv);
+                pr[c] = (i < F) && key[c] >= lb;
+                bm[c] = __ballot(pr[c]);
+                tot += __popcll(bm[c]);
+            }
+            if (tot == 0) continue;
+            if (scnt + tot > STG) flush();
+            uint32_t off = scnt;
+#pragma unroll
+            for (int c = 0; c < W; ++c) off += __popcll(bm[c] & lt);      // entries of lower lanes
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (pr[c]) { skey[w][off] = key[c]; sidx[w][off] = flat0 + (uint32_t)(i0 + c); ++off; }
+            scnt += tot;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    flush();
+}
+
+// gate <- 1 when the candidate set cannot contain the exact answer (or overflowed its buffer)
+__global__ void check_kernel(const SelCtl* __restrict__ ctl, int S, uint32_t Kseg, uint32_t capS, Head* __restrict__ head) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const uint32_t c = ctl[s].cand_cnt;
+        if (c < Kseg || c > capS) head->gate = 1;
+    }
+}
+
+// ---- stage 2: exact radix select on the candidate keys ---------------------------------------------
+__global__ __launch_bounds__(TPB) void cand_hist_kernel(const uint32_t* __restrict__ cand_key, uint32_t capS, const SelCtl* __restrict__ ctl,
+                                                        const SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p,
+                                                        const Head* __restrict__ head) {
+    if (head->gate) return;
+    __shared__ uint32_t hist[NBIN];
+    const int s = blockIdx.y, nb = 1 << BITS[p];
+    const uint32_t prefix = state[s].prefix, mask = state[s].mask;
+    const uint32_t n = ctl[s].cand_cnt;
+    const uint32_t* ck = cand_key + (size_t)s * capS;
+    for (int i = threadIdx.x; i < NBIN; i += TPB) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        const uint32_t key = ck[i];
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> SHIFT[p]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += TPB) { const uint32_t h = hist[i]; if (h) atomicAdd(&ghist[(long)s * NBIN + i], h); }
+}
+
+// candidates equal to the k-th value, when only some of them are selected (lowest flat index first)
+__global__ __launch_bounds__(TPB) void ties_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
+                                                   SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
+                                                   uint32_t* __restrict__ tie_idx, Head* __restrict__ head) {
+    if (head->gate) return;
+    const int s = blockIdx.y;
+    const SegState st = state[s];
+    if (!need_rank(st)) return;
+    const uint32_t n = ctl[s].cand_cnt;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        if (cand_key[(size_t)s * capS + i] == st.prefix) {
+            const uint32_t pos = atomicAdd(&ctl[s].tie_cnt, 1u);
+            if (pos < TIECAP) tie_idx[(size_t)s * TIECAP + pos] = cand_idx[(size_t)s * capS + i];
+        }
+    }
+}
+__global__ void check_ties_kernel(const SelCtl* __restrict__ ctl, int S, Head* __restrict__ head) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) if (ctl[s].tie_cnt > TIECAP) head->gate = 1;
+}
+
+// ---- stage 3: selected, positive candidates -> entry list + per-row / per-column counts -------------
+__global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
+                                                   const SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
+                                                   const uint32_t* __restrict__ tie_idx, int F, int L, uint32_t cap,
+                                                   uint32_t* __restrict__ sel_idx, float* __restrict__ sel_val,
+                                                   uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt,
+                                                   float* __restrict__ threshold, float e, Head* __restrict__ head,
+                                                   int32_t* __restrict__ overflow) {
+    if (head->gate) return;
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t sbase;
+    const int s = blockIdx.y;
+    const SegState st = state[s];
+    const uint32_t T = st.prefix;
+    const bool rank_ties = need_rank(st);
+    const uint32_t nt = rank_ties ? ctl[s].tie_cnt : 0;
+    const uint32_t* tl = tie_idx + (size_t)s * TIECAP;
+    const uint32_t n = ctl[s].cand_cnt;
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    const uint32_t* ck = cand_key + (size_t)s * capS;
+    const uint32_t* ci = cand_idx + (size_t)s * capS;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && threshold) {
+        const float kth = key_f32(T);
+        threshold[s] = (1.0f - e) * threshold[s] + e * (kth > 0.0f ? kth : 0.0f);      // topk.py:94-95, 131-132
+    }
+    auto taken = [&](uint32_t i) -> bool {
+        const uint32_t key = ck[i];
+        if (key <= 0x80000000u) return false;           // value <= 0: relu leaves nothing
+        if (key > T) return true;
+        if (key < T) return false;
+        if (!rank_ties) return true;
+        const uint32_t me = ci[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < nt; ++j) r += tl[j] < me;
+        return r < st.krem;
+    };
+    uint32_t cnt = 0;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TPB) cnt += taken(i);
+    uint32_t tot;
+    uint32_t off = block_excl_scan(cnt, sh, &tot);
+    if (threadIdx.x == 0) sbase = tot ? atomicAdd(&head->sel_cnt, tot) : 0u;
+    __syncthreads();
+    off += sbase;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += TPB) {
+        if (!taken(i)) continue;
+        const uint32_t idx = ci[i];
+        if (off < cap) { sel_idx[off] = idx; sel_val[off] = key_f32(ck[i]); }
+        else *overflow = 1;
+        ++off;
+        const uint32_t row = idx / (uint32_t)F, f = idx - row * (uint32_t)F;
+        atomicAdd(&row_cnt[row], 1u);
+        atomicAdd(&col_cnt[(row % (uint32_t)L) * (uint32_t)F + f], 1u);
+    }
+}
+
+// entry list -> CSR slots (order inside a row fixed afterwards by the row sort)
+__global__ void scatter_rows_kernel(const uint32_t* __restrict__ sel_idx, const float* __restrict__ sel_val, const Head* __restrict__ head,
+                                    uint32_t cap, int F, int L, const uint32_t* __restrict__ row_start, uint32_t* __restrict__ row_cursor,
+                                    int32_t* __restrict__ ent_col, float* __restrict__ ent_val) {
+    if (head->gate) return;
+    const uint32_t n = min(head->sel_cnt, cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint32_t idx = sel_idx[e];
+        const uint32_t row = idx / (uint32_t)F, f = idx - row * (uint32_t)F;
+        const uint32_t pos = row_start[row] + atomicAdd(&row_cursor[row], 1u);
+        if (pos < cap) { ent_col[pos] = (int32_t)((row % (uint32_t)L) * (uint32_t)F + f); ent_val[pos] = sel_val[e]; }
+    }
+}
+
+// rows mode: pack the [rows][k] compact rows (ascending feature id, valid count in row_cnt) into the CSR
+__global__ __launch_bounds__(TPB) void compact_rows_kernel(const int32_t* __restrict__ cidx, const float* __restrict__ cval, int k, int F, int L,
+                                                           int rows, const uint32_t* __restrict__ row_start, uint32_t cap,
+                                                           int32_t* __restrict__ ent_col, float* __restrict__ ent_val,
+                                                           int32_t* __restrict__ overflow) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t s = row_start[row], n = row_start[row + 1] - s;
+    const int colbase = (row % L) * F;
+    for (uint32_t e = threadIdx.x & 63; e < n; e += 64) {
+        if (s + e < cap) { ent_col[s + e] = colbase + cidx[(long)row * k + e]; ent_val[s + e] = cval[(long)row * k + e]; }
+        else *overflow = 1;
+    }
+}
+
+__global__ void masked_copy_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, long total, long n,
+                                   float* __restrict__ out, const int32_t* __restrict__ gate) {
+    if (gate && *gate == 0) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[i] = col_mask[i % n] ? x[i] : -INFINITY;
+}
+__global__ void publish_gate_kernel(const Head* __restrict__ head, int32_t* __restrict__ out) { *out = head->gate; }
+
+struct LPlan {
+    int S, RS, rows, ncols, rpb, NC;
+    uint32_t Kseg, ns, rank, capS;
+    size_t off_ctl, off_state, off_ghist, off_tie, off_rowcnt, off_rowcur, off_colcnt, off_colcur, zero_end;
+    size_t off_long, off_sample, off_ckey, off_cidx, off_sidx, off_sval, off_fbsel, off_fbbuild, total;
+};
+
+LPlan lplan(int B, int L, int F, int k, int mode) {
+    LPlan p;
+    p.S = mode == 2 ? L : 1;
+    p.RS = mode == 2 ? B : B * L;
+    p.rows = B * L; p.ncols = L * F;
+    const unsigned long long nseg = (unsigned long long)p.RS * F;
+    const unsigned long long K = (unsigned long long)k * p.RS;
+    p.Kseg = (uint32_t)K;
+    p.ns = (uint32_t)(nseg < NS_MAX ? nseg : NS_MAX);
+    const double m = (double)p.ns * (double)K / (double)nseg;
+    const double r = m + 8.0 * sqrt(m) + 32.0;
+    p.rank = r >= (double)p.ns ? p.ns : (uint32_t)r;
+    unsigned long long capS = 4ull * K + 65536ull;
+    if (capS > nseg) capS = nseg;
+    p.capS = (uint32_t)capS;
+    p.rpb = 16; if (p.rpb > p.RS) p.rpb = p.RS;
+    p.NC = (p.RS + p.rpb - 1) / p.rpb;
+    size_t o = sizeof(Head);
+    auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+    p.off_ctl = take((size_t)p.S * sizeof(SelCtl));
+    p.off_state = take((size_t)p.S * sizeof(SegState));
+    p.off_ghist = take((size_t)p.S * NBIN * 4);
+    p.off_tie = take(mode == 0 ? 0 : (size_t)p.S * TIECAP * 4);
+    p.off_rowcnt = take((size_t)p.rows * 4);
+    p.off_rowcur = take((size_t)p.rows * 4);
+    p.off_colcnt = take((size_t)p.ncols * 4);
+    p.off_colcur = take((size_t)p.ncols * 4);
+    p.zero_end = o;
+    p.off_long = take((size_t)(p.rows > p.ncols ? p.rows : p.ncols) * 4);
+    if (mode == 0) {
+        p.off_sample = p.off_ckey = p.off_cidx = o;
+        p.off_sidx = take((size_t)p.rows * k * 4);          // compact indices [rows][k]
+        p.off_sval = take((size_t)p.rows * k * 4);          // compact values
+        p.off_fbsel = p.off_fbbuild = o;
+    } else {
+        p.off_sample = take((size_t)p.S * p.ns * 4);
+        p.off_ckey = take((size_t)p.S * p.capS * 4);
+        p.off_cidx = take((size_t)p.S * p.capS * 4);
+        p.off_sidx = take((size_t)K * p.S * 4);
+        p.off_sval = take((size_t)K * p.S * 4);
+        p.off_fbsel = take(clt_topk_segmented_workspace_bytes(B, L, F, mode == 2));
+        p.off_fbbuild = take(clt_sparse_build_workspace_bytes(B, L, F));
+    }
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" {
+size_t clt_select_lists_workspace_bytes(int B, int L, int F, int k, int mode) {
+    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 0 || mode > 2) return 0;
+    return lplan(B, L, F, k > F ? F : k, mode).total;
+}
+
+int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, int F, int k, int mode, float* threshold,
+                         float ema_e, uint32_t cap, uint32_t* row_start, int32_t* ent_col, float* ent_val,
+                         uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent, uint8_t* fired,
+                         uint32_t* total, int32_t* overflow, float* dense_scratch, int32_t* used_fallback, void* ws,
+                         size_t wsb, void* stp) {
+    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 0 || mode > 2 || cap == 0) return CLT_ERR_SHAPE;
+    if (k > F) return CLT_ERR_K_GT_F;
+    const unsigned long long nall = (unsigned long long)B * L * F;
+    if (nall >= 0xffffffffull || (unsigned long long)L * F >= 0x7fffffffull) return CLT_ERR_RANGE;
+    if (mode == 0 && k > 2048) return CLT_ERR_RANGE;
+    if (mode != 0 && !dense_scratch) return CLT_ERR_SHAPE;
+    hipStream_t st = as_stream(stp);
+    const int rows = B * L, ncols = L * F;
+    if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (used_fallback && hipMemsetAsync(used_fallback, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (k == 0) {                                          // topk.py:86-87: nothing selected, no threshold update
+        if (hipMemsetAsync(row_start, 0, (size_t)(rows + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(col_start, 0, (size_t)(ncols + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(fired, 0, (size_t)ncols, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(total, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        return CLT_OK;
+    }
+    const LPlan p = lplan(B, L, F, k, mode);
+    if (!ws || wsb < p.total) return CLT_ERR_WORKSPACE;
+    char* w8 = (char*)ws;
+    Head* head = (Head*)w8;
+    SelCtl* ctl = (SelCtl*)(w8 + p.off_ctl);
+    SegState* state = (SegState*)(w8 + p.off_state);
+    uint32_t* ghist = (uint32_t*)(w8 + p.off_ghist);
+    uint32_t* tie_idx = (uint32_t*)(w8 + p.off_tie);
+    uint32_t* row_cnt = (uint32_t*)(w8 + p.off_rowcnt);
+    uint32_t* row_cur = (uint32_t*)(w8 + p.off_rowcur);
+    uint32_t* col_cnt = (uint32_t*)(w8 + p.off_colcnt);
+    uint32_t* col_cur = (uint32_t*)(w8 + p.off_colcur);
+    int32_t* long_list = (int32_t*)(w8 + p.off_long);
+    if (hipMemsetAsync(ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
+    const int32_t* gate = nullptr;                         // rows mode has no probabilistic stage
+
+    if (mode == 0) {
+        int32_t* cidx = (int32_t*)(w8 + p.off_sidx);
+        float* cval = (float*)(w8 + p.off_sval);
+        const int rc = clt_internal_topk_rows(x, nullptr, rows, F, k, cidx, cval, col_mask, L, row_cnt, col_cnt, st);
+        if (rc != CLT_OK) return rc;
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 0);
+        hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, cidx, cval, k, F, L, rows, row_start, cap,
+                           ent_col, ent_val, overflow);
+    } else {
+        uint32_t* sample = (uint32_t*)(w8 + p.off_sample);
+        uint32_t* ckey = (uint32_t*)(w8 + p.off_ckey);
+        uint32_t* cidx = (uint32_t*)(w8 + p.off_cidx);
+        uint32_t* sidx = (uint32_t*)(w8 + p.off_sidx);
+        float* sval = (float*)(w8 + p.off_sval);
+        gate = &head->gate;
+        hipLaunchKernelGGL(sample_kernel, dim3(p.S), dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.ns, p.rank, p.Kseg, sample,
+                           state, ctl);
+        const dim3 fgrid(p.NC, p.S);
+        if (F % 4 == 0 && aligned16(x))
+            hipLaunchKernelGGL((filter_kernel<true>), fgrid, dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
+        else
+            hipLaunchKernelGGL((filter_kernel<false>), fgrid, dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
+        hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, st, ctl, p.S, p.Kseg, p.capS, head);
+        int nbk = (int)((p.capS + TPB * 16 - 1) / (TPB * 16)); if (nbk > 512) nbk = 512; if (nbk < 1) nbk = 1;
+        const dim3 cgrid(nbk, p.S);
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(cand_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, p.capS, ctl, state, ghist, pass, head);
+            hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, pass, gate, 0);
+        }
+        hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_idx, head);
+        hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, ctl, p.S, head);
+        const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
+        const uint32_t capsel = cap < kall ? cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
+        hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_idx, F, L, capsel, sidx, sval,
+                           row_cnt, col_cnt, threshold, ema_e, head, overflow);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 0);
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, row_start, row_cur, ent_col,
+                           ent_val);
+        hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, row_start, rows, ent_col, ent_val,
+                           (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
+        hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, row_start, ent_col, ent_val, (int32_t*)nullptr, long_list,
+                           &head->long_rows, gate, 0);
+    }
+    // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, col_start, (uint32_t*)nullptr, fired, gate, 0);
+    hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap, col_start,
+                       col_cur, csc_tok, csc_val, csc_ent, gate, 0);
+    hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val, csc_ent,
+                       long_list, &head->long_cols, gate, 0);
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
+                       &head->long_cols, gate, 0);
+    CLT_LAUNCH_CHECK();
+
+    if (mode != 0) {                                       // exhaustive path, enqueued always, runs only when gated in
+        const float* src = x;
+        if (col_mask) {
+            hipLaunchKernelGGL(masked_copy_kernel, dim3(4096), dim3(TPB), 0, st, x, col_mask, (long)nall, (long)ncols, dense_scratch, gate);
+            src = dense_scratch;
+        }
+        void* fbsel = w8 + p.off_fbsel;
+        void* fbbuild = w8 + p.off_fbbuild;
+        int rc = clt_internal_topk_segmented(src, dense_scratch, B, L, F, k, mode == 2, threshold, ema_e, fbsel,
+                                             p.off_fbbuild - p.off_fbsel, st, gate);
+        if (rc != CLT_OK) return rc;
+        const size_t bb = clt_sparse_build_workspace_bytes(B, L, F);
+        if (hipMemsetAsync(fbbuild, 0, bb, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        rc = clt_internal_sparse_build(dense_scratch, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
+                                       csc_ent, fired, total, overflow, fbbuild, bb, st, gate);
+        if (rc != CLT_OK) return rc;
+        if (used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, used_fallback);
+    }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+}  // extern "C"

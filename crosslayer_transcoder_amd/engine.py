@@ -41,6 +41,34 @@ def _select(nl, pre):
                               nl.e or 0.0)
 
 
+def _select_lists(nl, pre, col_mask=None):
+    """TopK-family training forward straight to the active-entry lists (no dense feature tensor).  `col_mask`
+    (uint8 [L,F]) restricts the candidates to the masked-in features: where(mask, pre, -inf) (clt_lightning.py:544-545)."""
+    Bn, L, F = pre.shape
+    assert nl.k <= F
+    if isinstance(nl, PerLayerTopK):
+        if nl.k > 2048:                         # compact-row buffer limit of the rows kernel: go through the dense result
+            x = pre if col_mask is None else ops.mask_dead(pre, col_mask)
+            return ops.sparse_build(ops.topk_rows(x, nl.k), _list_capacity(nl, Bn, L, F))
+        return ops.select_lists(pre, nl.k, ops.SELECT_ROWS, col_mask=col_mask)
+    if nl.k > 0 and nl.e is None:
+        raise TypeError("BatchTopK needs `e` (threshold EMA rate) for training")
+    mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
+    return ops.select_lists(pre, nl.k, mode, nl.threshold if nl.k > 0 else None, nl.e or 0.0, col_mask)
+
+
+class StepOutput(dict):
+    """Result of training_step.  In the sparse regime the dense `features` tensor is not part of the computation;
+    it is materialised from the lists on first access (tests, metric logging)."""
+
+    def __missing__(self, key):
+        if key == "features" and "lists" in self:
+            S = self["lists"]
+            self[key] = ops.sparse_scatter_dense(S, S.csc_val)
+            return self[key]
+        raise KeyError(key)
+
+
 def _encoder_operand(enc):
     """Feature-major [L,F,d] encoder weight in the active precision.  In bf16 mode a persistent bf16 shadow is
     kept on the module; the fused Adam row pass refreshes it, any other in-place change of W (optimizer,
@@ -175,7 +203,10 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
 
     theta = None
-    if isinstance(nl, JumpReLU):
+    feat = S = None
+    if sparse:
+        S = _select_lists(nl, pre)
+    elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
     elif isinstance(nl, ReLU):
@@ -191,7 +222,6 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     want_ys = kind == "topk"
 
     if sparse:
-        S = ops.sparse_build(feat, _list_capacity(nl, Bn, L, F))
         r = D.sparse_fwd(S)
         fired = S.fired
     else:
@@ -202,14 +232,15 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     terms = {"mse": (loss_sum[0] / N).float()}
     dead, dead_cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F)
-    out = {"terms": terms, "grads": grads, "dead": dead, "features": feat, "recons_norm": r, "pre_actvs": pre}
+    out = StepOutput(terms=terms, grads=grads, dead=dead, recons_norm=r, pre_actvs=pre)
+    if feat is not None:
+        out["features"] = feat
 
     if sparse:
         S2 = g_aux = None
         if kind == "topk":
             aux = mod.topk_aux
-            dead_feat = _select(aux, ops.mask_dead(pre, dead))
-            S2 = ops.sparse_build(dead_feat, _list_capacity(aux, Bn, L, F))
+            S2 = _select_lists(aux, pre, dead)
             aux_r = D.sparse_fwd(S2)
             aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
             terms["aux"] = (aux_sum[0] / N).float()

@@ -418,7 +418,7 @@ def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wei
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
     __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
-                 "csc_ent", "fired", "total", "overflow")
+                 "csc_ent", "fired", "total", "overflow", "used_fallback")
 
 
 def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
@@ -443,6 +443,53 @@ def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
     call("clt_sparse_build_f32", feat.data_ptr(), Bn, L, F, s.cap, s.row_start.data_ptr(), s.ent_col.data_ptr(),
          s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(), s.csc_ent.data_ptr(),
          s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return s
+
+
+def _empty_lists(Bn, L, F, cap, dev) -> SparseLists:
+    s = SparseLists()
+    s.B, s.L, s.F, s.cap = Bn, L, F, int(cap)
+    i32 = dict(dtype=torch.int32, device=dev)
+    s.row_start = torch.empty(Bn * L + 1, **i32)
+    s.ent_col = torch.empty(cap, **i32)
+    s.ent_val = torch.empty(cap, dtype=torch.float32, device=dev)
+    s.col_start = torch.empty(L * F + 1, **i32)
+    s.csc_tok = torch.empty(cap, **i32)
+    s.csc_val = torch.empty(cap, dtype=torch.float32, device=dev)
+    s.csc_ent = torch.empty(cap, **i32)
+    s.fired = torch.empty(L, F, dtype=torch.uint8, device=dev)
+    s.total = torch.empty(1, **i32)
+    s.overflow = torch.empty(1, **i32)
+    return s
+
+
+SELECT_ROWS, SELECT_BATCH, SELECT_LAYER = 0, 1, 2
+
+
+def select_lists(x: torch.Tensor, k: int, mode: int, threshold: Optional[torch.Tensor] = None, e: float = 0.0,
+                 col_mask: Optional[torch.Tensor] = None, cap: Optional[int] = None) -> SparseLists:
+    """TopK-family selection straight to the active-entry lists (no dense feature tensor).  mode: SELECT_ROWS /
+    SELECT_BATCH / SELECT_LAYER.  `threshold` (modes 1/2) is EMA-updated in place.  The returned lists carry
+    `used_fallback` (device int32 [1]): 1 when the exhaustive path had to run."""
+    _chk(x)
+    Bn, L, F = x.shape
+    if cap is None:
+        cap = max(1, min(k, F) * Bn * L)
+    s = _empty_lists(Bn, L, F, cap, x.device)
+    nb = lib.clt_select_lists_workspace_bytes(Bn, L, F, k, mode)
+    ws = workspace(nb, x.device)
+    dense = torch.empty_like(x) if mode != SELECT_ROWS else None      # fallback scratch (untouched on the fast path)
+    fb = torch.empty(1, dtype=torch.int32, device=x.device)
+    if col_mask is not None:
+        _chk(col_mask, torch.uint8)
+    if threshold is not None:
+        _chk(threshold)
+    call("clt_select_lists_f32", x.data_ptr(), col_mask.data_ptr() if col_mask is not None else None, Bn, L, F, k, mode,
+         threshold.data_ptr() if threshold is not None else None, float(e or 0.0), s.cap, s.row_start.data_ptr(),
+         s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(),
+         s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
+         dense.data_ptr() if dense is not None else None, fb.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    s.used_fallback = fb
     return s
 
 

@@ -180,6 +180,19 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
                          float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                          uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace, size_t ws_bytes,
                          void* stream);
+/* Selection straight to lists (replaces topk.py:58-61, 84-91, 117-128 + the list build above when the dense
+ * feature tensor is not needed).  mode 0: k of F per (b,l) row (k <= 2048); 1: global k*B*L; 2: per layer k*B.
+ * x: [B][L][F] fp32 pre-activations; col_mask (optional, uint8 [L*F]): positions with mask 0 count as -inf
+ * (where(dead, x, -inf), clt_lightning.py:544-545).  threshold[S] EMA as in clt_topk_segmented_f32 (modes 1/2).
+ * Lists: exactly those clt_sparse_build_f32 would build from the dense selection result.  dense_scratch
+ * ([B][L][F] floats, modes 1/2): scratch of the exhaustive fallback, which runs — chosen on the device, no host
+ * sync — only when the sampled candidate set cannot contain the answer; used_fallback[0] (optional) reports it. */
+size_t clt_select_lists_workspace_bytes(int B, int L, int F, int k, int mode);
+int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, int F, int k, int mode, float* threshold,
+                         float ema_e, uint32_t cap, uint32_t* row_start, int32_t* ent_col, float* ent_val,
+                         uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent, uint8_t* fired,
+                         uint32_t* total, int32_t* overflow, float* dense_scratch, int32_t* used_fallback,
+                         void* workspace, size_t ws_bytes, void* stream);
 /* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
  * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
  * Wptr: DEVICE array of L device pointers. */

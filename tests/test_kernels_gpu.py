@@ -382,3 +382,77 @@ def test_sparse_row_pass_two_lists_and_encoder(ops):
     want = torch.stack([xs[:, l].double() @ Wt[l].cpu().double().T for l in range(L)], 1) * (f2 > 0)
     got = ops.sparse_scatter_dense(S2, ops.sparse_reduce_dots(dots2, S2, False)).cpu()
     assert_close(got, want.float(), **tol(want), what="dots of the 2nd list")
+
+
+def _lists_equal(A, Bl, what):
+    n = int(A.total)
+    assert n == int(Bl.total), f"{what}: total {n} vs {int(Bl.total)}"
+    assert int(A.overflow) == 0 and int(Bl.overflow) == 0
+    for name in ("row_start", "col_start", "fired"):
+        assert torch.equal(getattr(A, name), getattr(Bl, name)), f"{what}: {name}"
+    for name in ("ent_col", "ent_val", "csc_tok", "csc_val", "csc_ent"):
+        assert torch.equal(getattr(A, name)[:n], getattr(Bl, name)[:n]), f"{what}: {name}"
+
+
+@pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (16, 2, 32, 4), (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
+                                     (2, 2, 64, 64), (512, 4, 8192, 16)])
+def test_select_lists_matches_dense_selection(ops, B, L, F, k):
+    """Selection straight to lists == dense (oracle-checked) selection followed by the list build, bit for bit,
+    in every mode, with and without the dead-feature mask; EMA thresholds agree."""
+    x = _rand(B, L, F, seed=3 * B + F).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    mask = (torch.rand(L, F, generator=g) < 0.3).to(torch.uint8).to(DEV)
+    cap = k * B * L
+    for cm in (None, mask):
+        xm = x if cm is None else ops.mask_dead(x, cm)
+        want = ops.sparse_build(ops.topk_rows(xm, k), cap)
+        got = ops.select_lists(x, k, ops.SELECT_ROWS, col_mask=cm)
+        _lists_equal(got, want, f"rows mask={cm is not None}")
+        for mode, per_layer, S in ((ops.SELECT_BATCH, False, 1), (ops.SELECT_LAYER, True, L)):
+            t1, t2 = torch.full((S,), 0.25, device=DEV), torch.full((S,), 0.25, device=DEV)
+            want = ops.sparse_build(ops.topk_segmented(xm, k, per_layer, t1, 0.1), cap)
+            got = ops.select_lists(x, k, mode, t2, 0.1, cm)
+            _lists_equal(got, want, f"mode {mode} mask={cm is not None}")
+            assert torch.equal(t1, t2), "threshold EMA"
+    # the oracle, directly, for the unmasked batch mode
+    ref, _, _ = O.batch_topk_fwd(x.cpu(), k)
+    got = ops.select_lists(x, k, ops.SELECT_BATCH, torch.zeros(1, device=DEV), 0.1)
+    assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), ref)
+
+
+def test_select_lists_ties_fallback_and_edges(ops):
+    """Heavy ties: few ties -> ranked by index on the candidate list; thousands of ties -> the device-side gate
+    switches to the exhaustive path.  Both must equal the oracle's rule (larger value, then lower index)."""
+    g = torch.Generator().manual_seed(0)
+    t = torch.randint(0, 6, (40, 3, 512), generator=g).float() - 1.0          # ~10k ties at the threshold value
+    few = _rand(40, 3, 512, seed=4)
+    few[3, 1, 7] = few[5, 2, 9] = few[1, 0, 100] = few[30, 2, 500] = 0.75      # 4 equal values straddling a cut
+    for x, expect_fb in ((t, True), (few, False)):
+        xd = x.to(DEV)
+        for k in (1, 7, 100):
+            got = ops.select_lists(xd, k, ops.SELECT_BATCH, None, 0.0)
+            assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), O.batch_topk_fwd(x, k)[0])
+            if expect_fb and k >= 7:
+                assert int(got.used_fallback) == 1
+            if not expect_fb:
+                assert int(got.used_fallback) == 0
+            got = ops.select_lists(xd, k, ops.SELECT_LAYER, None, 0.0)
+            assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), O.per_layer_batch_topk_fwd(x, k)[0])
+            got = ops.select_lists(xd, k, ops.SELECT_ROWS)
+            assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), O.per_layer_topk_fwd(x, k)[0])
+    # exact cut through the 4 equal values: choose k so that the k-th value is 0.75
+    flat = few.reshape(-1)
+    rank = int((flat > 0.75).sum())
+    for kk in (rank + 1, rank + 2, rank + 3):
+        if kk % (40 * 3) == 0:
+            k = kk // 120
+            got = ops.select_lists(few.to(DEV), k, ops.SELECT_BATCH, None, 0.0)
+            assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), O.batch_topk_fwd(few, k)[0])
+    x = (torch.rand(3, 4, 5) + 0.1).to(DEV)                                      # k = 0, k = F, k > F
+    for mode in (ops.SELECT_ROWS, ops.SELECT_BATCH, ops.SELECT_LAYER):
+        z = ops.select_lists(x, 0, mode)
+        assert int(z.total) == 0 and torch.equal(ops.sparse_scatter_dense(z, z.csc_val), torch.zeros_like(x))
+        full = ops.select_lists(x, 5, mode)
+        assert torch.equal(ops.sparse_scatter_dense(full, full.csc_val), x)
+        with pytest.raises(AssertionError):
+            ops.select_lists(x, 6, mode)
