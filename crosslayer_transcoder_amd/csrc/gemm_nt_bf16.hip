@@ -1,0 +1,168 @@
+// Fast path of clt_gemm_bf16 for the "NT" form  C[M][N] (+)= A[M][K] * B[N][K]^T + bias[N]  (both operands
+// k-contiguous): the encoder forward of the step (reference model/clt.py:157-165 under bf16-mixed; A = standardized
+// activations [tokens][d], B = feature-major encoder weight [features][d]) and every other NT-shaped contraction.
+//
+// gfx950 design: 256 (B rows) x 256 (A rows) x 64 block tile, 512 threads = 8 waves as 2 x 4, each wave 128 x 64 of
+// v_mfma_f32_16x16x32_bf16 tiles.  B rows ride the MFMA "M" index and A rows the "N" index, so a lane's four
+// accumulator registers are four CONSECUTIVE output columns of one C row: the epilogue is one 16-byte store per
+// lane per tile.  Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+// buffered (2 x 64 KB); the LDS image is lane-linear 128-byte rows whose 16-byte chunks are XOR-swizzled with
+// bits 1..3 of the row — applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads —
+// which spreads the 16 rows of a fragment over all 16 slots of the 256-byte bank row.  Blocks are remapped so
+// that each XCD (own L2) works on a contiguous range of tiles.
+#include <stdlib.h>
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int TB = 256, TA = 256, TK = 64;              // tile: B rows (C columns), A rows (C rows), k
+constexpr int OP_BYTES = 256 * TK * 2;                  // one operand tile in LDS (32 KiB)
+constexpr int STAGE_BYTES = 2 * OP_BYTES;               // B tile | A tile
+constexpr int EROW = 512 + 16;                          // epilogue transposition: padded row of 128 floats
+constexpr int LDS_BYTES = 8 * 32 * EROW;                // max(double-buffered staging 128 KiB, epilogue 132 KiB)
+static_assert(LDS_BYTES >= 2 * STAGE_BYTES, "LDS");
+
+extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
+
+#define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
+                                                        (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+__global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K, long lda, long ldb,
+                                                           long ldc, long sA, long sB, long sC, const float* __restrict__ bias,
+                                                           long sBias, int accumulate, int tilesA, int tilesB, int diag) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
+    // ---- block -> (batch, tile) with an XCD-aware, bijective remap ------------------------------------
+    const int nwg = tilesA * tilesB;
+    const int batch = blockIdx.x / nwg;
+    int lid = blockIdx.x - batch * nwg;
+    {
+        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+    }
+    const int ta = lid % tilesA, tb = lid / tilesA;
+    const int a0 = ta * TA, b0 = tb * TB;
+    A += (long)batch * sA; B += (long)batch * sB; C += (long)batch * sC;
+    if (bias) bias += (long)batch * sBias;
+
+    // ---- staging addresses: per glds instruction a wave fills 8 rows x 128 B ---------------------------
+    const uint16_t* gB[4];
+    const uint16_t* gA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + w) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);           // logical k-chunk stored at this physical slot
+        int rb = b0 + row; rb = rb < N ? rb : N - 1;               // clamp: rows past the edge are loaded, never stored
+        int ra = a0 + row; ra = ra < M ? ra : M - 1;
+        gB[i] = B + (long)rb * ldb + chunk * 8;
+        gA[i] = A + (long)ra * lda + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = nt_smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GLDS16(gB[i] + (long)kt * TK, base + (i * 8 + w) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GLDS16(gA[i] + (long)kt * TK, base + OP_BYTES + (i * 8 + w) * 1024);
+    };
+
+    // ---- fragment read offsets (bytes inside an operand tile) ------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    int offB[2], offA[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int phys = (ks * 4 + fq) ^ (fr >> 1);
+        offB[ks] = (wm * 128 + fr) * 128 + phys * 16;
+        offA[ks] = OP_BYTES + (wn * 64 + fr) * 128 + phys * 16;
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int nk = (diag & 2) ? 0 : K / TK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const unsigned char* base = nt_smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fb[8], fa[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fa[n] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + n * 2048);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) fb[m] = *reinterpret_cast<const bf16x8*>(base + offB[ks] + m * 2048);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
+    // transposes its 64 x 128 sub-tile through a private LDS region (two halves of 32 rows, 528-byte padded rows:
+    // conflict-free b128 writes) and stores 512-byte contiguous row segments: 2 rows per wave-instruction.
+    // (The last K-step's trailing barrier has retired every read of the staging buffers.)
+    unsigned char* ebuf = nt_smem + w * (32 * EROW);
+    const int er = lane >> 5, ec = (lane & 31) * 4;
+    const int colw = b0 + wm * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                *reinterpret_cast<f32x4*>(ebuf + (n2 * 16 + fr) * EROW + (m * 16 + fq * 4) * 4) = acc[m][h * 2 + n2];
+        __builtin_amdgcn_wave_barrier();
+        const int col = colw + ec;
+        f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (bias && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int lr = it * 2 + er;
+            const int row = a0 + wn * 64 + h * 32 + lr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4);
+            if (row < M && col < N) {
+                float* dst = C + (long)row * ldc + col;
+                v += bv;
+                if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); v += old; }
+                if (diag & 1) { asm volatile("" ::"v"(v)); } else *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+}  // namespace
+
+// Returns CLT_OK when the fast kernel was launched, 1 when the shape/alignment does not qualify (caller falls back
+// to the generic kernel), or a negative error.
+int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
+                              int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
+                              hipStream_t st) {
+    const bool ok = K % TK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
+                    sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
+                    (long)M * N >= 256L * 256L;
+    if (!ok) return 1;
+    const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
+    const long nblk = (long)tilesA * tilesB * batch;
+    if (nblk > 0x7fffffffL) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((unsigned)nblk), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, ldc, sA, sB,
+                       sC, bias, sBias, accumulate, tilesA, tilesB, getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0);
+    CLT_LAUNCH_CHECK();
+    return CLT_OK;
+}

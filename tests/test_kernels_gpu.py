@@ -456,3 +456,30 @@ def test_select_lists_ties_fallback_and_edges(ops):
         assert torch.equal(ops.sparse_scatter_dense(full, full.csc_val), x)
         with pytest.raises(AssertionError):
             ops.select_lists(x, 6, mode)
+
+
+@pytest.mark.parametrize("Bn,L,d,F", [(300, 2, 128, 520), (256, 1, 64, 256), (1000, 3, 192, 1028), (513, 2, 768, 260)])
+def test_gemm_nt_fast_path(ops, Bn, L, d, F):
+    """The glds / 16x16x32 NT kernel (K % 64 == 0, M*N >= 256^2): encoder forward with bias, edge tiles in both
+    directions, batched; plus accumulate and the A = I asymmetric-B layout check."""
+    bf = torch.bfloat16
+    xs, Wt = _rand(Bn, L, d, seed=1).to(bf), _rand(L, F, d, seed=2, scale=d ** -0.5).to(bf)
+    b = _rand(L, F, seed=3, scale=0.1)
+    ref = torch.stack([xs[:, l].double() @ Wt[l].double().T + b[l].double() for l in range(L)], 1)
+    got = ops.encoder_fwd(xs.to(DEV), Wt.to(DEV), b.to(DEV))
+    assert_close(got, ref, **tol(ref, 2e-6), what="NT fast path")
+    # dgrad-shaped call (accumulate into an existing C): dx += dpre @ W^T uses transB with K = F
+    if F % 64 == 0:
+        dpre = _rand(Bn, L, F, seed=4).to(bf)
+        Wd = _rand(L, d, F, seed=5, scale=0.05).to(bf)                 # [N = d][K = F] rows
+        out = torch.zeros(Bn, L, d, device=DEV)
+        for rep in range(2):
+            ops._gemm("clt_gemm_bf16", dpre.to(DEV), 0, Wd.to(DEV), 0, out, 0, Bn, d, F, L * F, F, L * d, False, True, batch=L,
+                      sA=F, sB=d * F, sC=d, accumulate=rep == 1)
+        want = 2 * torch.stack([dpre[:, l].double() @ Wd[l].double().T for l in range(L)], 1)
+        assert_close(out, want, **tol(want, 2e-6), what="NT accumulate")
+    n = 256
+    Bm = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(bf)   # exactly representable, asymmetric
+    eye = torch.eye(n).to(bf)
+    out = ops.encoder_fwd(eye.reshape(n, 1, n).to(DEV), Bm.reshape(1, n, n).to(DEV), None)
+    assert torch.equal(out.cpu().reshape(n, n), Bm.float().T)
