@@ -24,36 +24,41 @@ namespace {
 constexpr uint32_t NS_MAX = 131072, TIECAP = 4096;
 constexpr int STG = 512;                      // per-wave candidate staging entries in LDS
 
-struct SelCtl { uint32_t lb, cand_cnt, tie_cnt, pad; };
+struct SelCtl { uint32_t lb, cand_cnt, pad0, pad1; };
+struct Shard { int world, rank; uint32_t f_off, F_global; };   // feature-axis sharding: this rank owns columns [f_off, f_off + F)
 struct Head { int32_t gate; uint32_t sel_cnt, long_rows, long_cols; uint32_t pad[60]; };   // 256 B, zeroed per call
 
 __device__ __forceinline__ long lseg_row(int q, int s, int S, int L) { return S == 1 ? (long)q : (long)q * L + s; }
 
 // ---- stage 0: lower bound from a sample -----------------------------------------------------------
-__global__ __launch_bounds__(TPB) void sample_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, int F, int L,
-                                                     int S, int RS, uint32_t ns, uint32_t rank, uint32_t Kseg,
-                                                     uint32_t* __restrict__ sample, SegState* __restrict__ state,
-                                                     SelCtl* __restrict__ ctl) {
+// gather (many blocks: the reads are random, latency-bound) ...
+__global__ __launch_bounds__(TPB) void sample_gather_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, int F, int L,
+                                                            int S, int RS, uint32_t ns, uint32_t* __restrict__ sample) {
+    const int s = blockIdx.y;
+    const unsigned long long nseg = (unsigned long long)RS * F;
+    const uint32_t j = blockIdx.x * TPB + threadIdx.x;
+    if (j >= ns) return;
+    const unsigned long long e = (ns == nseg) ? j : ((((unsigned long long)j + 1) * 0x9E3779B97F4A7C15ull) >> 20) % nseg;
+    const int q = (int)(e / F), i = (int)(e % F);
+    const long row = lseg_row(q, s, S, L);
+    float v = x[row * F + i];
+    if (col_mask && !col_mask[(row % L) * F + i]) v = -INFINITY;
+    sample[(size_t)s * ns + j] = f32_key(v);
+}
+
+// ... then one block per segment: exact rank-th largest sampled key = the lower bound
+__global__ __launch_bounds__(TPB) void sample_kernel(uint32_t ns, uint32_t rank, uint32_t Kseg, const uint32_t* __restrict__ sample,
+                                                     SegState* __restrict__ state, SelCtl* __restrict__ ctl) {
     __shared__ uint32_t hist[NBIN];
     __shared__ uint32_t sh[8];
     __shared__ uint32_t res[4];
     const int s = blockIdx.x;
-    const unsigned long long nseg = (unsigned long long)RS * F;
-    uint32_t* smp = sample + (size_t)s * ns;
+    const uint32_t* smp = sample + (size_t)s * ns;
     if (threadIdx.x == 0) { SegState st; st.prefix = 0; st.mask = 0; st.krem = Kseg; st.eq_total = 0; state[s] = st; }
     if (rank >= ns) {                          // tiny problem: every element is a candidate
         if (threadIdx.x == 0) ctl[s].lb = 0u;
         return;
     }
-    for (uint32_t j = threadIdx.x; j < ns; j += TPB) {
-        const unsigned long long e = (ns == nseg) ? j : ((((unsigned long long)j + 1) * 0x9E3779B97F4A7C15ull) >> 20) % nseg;
-        const int q = (int)(e / F), i = (int)(e % F);
-        const long row = lseg_row(q, s, S, L);
-        float v = x[row * F + i];
-        if (col_mask && !col_mask[(row % L) * F + i]) v = -INFINITY;
-        smp[j] = f32_key(v);
-    }
-    __syncthreads();
     uint32_t prefix = 0, mask = 0, krem = rank;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -141,23 +146,24 @@ __global__ __launch_bounds__(TPB) void filter_kernel(const float* __restrict__ x
     flush();
 }
 
-// gate <- 1 when the candidate set cannot contain the exact answer (or overflowed its buffer)
-__global__ void check_kernel(const SelCtl* __restrict__ ctl, int S, uint32_t Kseg, uint32_t capS, Head* __restrict__ head) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const uint32_t c = ctl[s].cand_cnt;
-        if (c < Kseg || c > capS) head->gate = 1;
-    }
+// gate <- 1 when the candidate set cannot contain the exact answer (or overflowed its buffer).
+// tot[s] = candidates of segment s summed over all shards (== the local count on one GPU).
+__global__ void publish_counts_kernel(const SelCtl* __restrict__ ctl, int S, uint32_t* __restrict__ tot) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) tot[s] = ctl[s].cand_cnt;
+}
+__global__ void check_kernel(const SelCtl* __restrict__ ctl, const uint32_t* __restrict__ tot, int S, uint32_t Kseg, uint32_t capS,
+                             Head* __restrict__ head) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+        if (tot[s] < Kseg || ctl[s].cand_cnt > capS) head->gate = 1;
 }
 
 // ---- stage 2: exact radix select on the candidate keys ---------------------------------------------
 __global__ __launch_bounds__(TPB) void cand_hist_kernel(const uint32_t* __restrict__ cand_key, uint32_t capS, const SelCtl* __restrict__ ctl,
-                                                        const SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p,
-                                                        const Head* __restrict__ head) {
-    if (head->gate) return;
+                                                        const SegState* __restrict__ state, uint32_t* __restrict__ ghist, int p) {
     __shared__ uint32_t hist[NBIN];
     const int s = blockIdx.y, nb = 1 << BITS[p];
     const uint32_t prefix = state[s].prefix, mask = state[s].mask;
-    const uint32_t n = ctl[s].cand_cnt;
+    const uint32_t n = min(ctl[s].cand_cnt, capS);
     const uint32_t* ck = cand_key + (size_t)s * capS;
     for (int i = threadIdx.x; i < NBIN; i += TPB) hist[i] = 0;
     __syncthreads();
@@ -169,30 +175,51 @@ __global__ __launch_bounds__(TPB) void cand_hist_kernel(const uint32_t* __restri
     for (int i = threadIdx.x; i < nb; i += TPB) { const uint32_t h = hist[i]; if (h) atomicAdd(&ghist[(long)s * NBIN + i], h); }
 }
 
+// Tie exchange block of one shard: cnt[S] | gate | idx[S][TIECAP]  (all uint32); the blocks of all shards are
+// contiguous so that one all-gather fills them.  Indices are GLOBAL flat indices (row * F_global + f_off + f).
+__device__ __forceinline__ size_t tie_block_words(int S) { return (size_t)S + 1 + (size_t)S * TIECAP; }
+__device__ __forceinline__ uint32_t global_index(uint32_t idx, int F, const Shard& sd) {
+    const uint32_t row = idx / (uint32_t)F, f = idx - row * (uint32_t)F;
+    return row * sd.F_global + sd.f_off + f;
+}
+
 // candidates equal to the k-th value, when only some of them are selected (lowest flat index first)
 __global__ __launch_bounds__(TPB) void ties_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
-                                                   SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
-                                                   uint32_t* __restrict__ tie_idx, Head* __restrict__ head) {
+                                                   const SelCtl* __restrict__ ctl, const SegState* __restrict__ state, int S, int F,
+                                                   Shard sd, uint32_t* __restrict__ tie_region, const Head* __restrict__ head) {
     if (head->gate) return;
     const int s = blockIdx.y;
     const SegState st = state[s];
     if (!need_rank(st)) return;
+    uint32_t* blk = tie_region + sd.rank * tie_block_words(S);
     const uint32_t n = ctl[s].cand_cnt;
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
         if (cand_key[(size_t)s * capS + i] == st.prefix) {
-            const uint32_t pos = atomicAdd(&ctl[s].tie_cnt, 1u);
-            if (pos < TIECAP) tie_idx[(size_t)s * TIECAP + pos] = cand_idx[(size_t)s * capS + i];
+            const uint32_t pos = atomicAdd(&blk[s], 1u);
+            if (pos < TIECAP) blk[S + 1 + (size_t)s * TIECAP + pos] = global_index(cand_idx[(size_t)s * capS + i], F, sd);
         }
     }
 }
-__global__ void check_ties_kernel(const SelCtl* __restrict__ ctl, int S, Head* __restrict__ head) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) if (ctl[s].tie_cnt > TIECAP) head->gate = 1;
+// own tie block: overflow -> gate; publish the local gate in the block so that the gather carries it
+__global__ void check_ties_kernel(int S, Shard sd, uint32_t* __restrict__ tie_region, Head* __restrict__ head) {
+    uint32_t* blk = tie_region + sd.rank * tie_block_words(S);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) if (blk[s] > TIECAP) head->gate = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[S] = (uint32_t)head->gate;
+}
+// after the gather: gate = OR over shards
+__global__ void merge_gate_kernel(int S, int world, const uint32_t* __restrict__ tie_region, Head* __restrict__ head) {
+    if (threadIdx.x == 0) {
+        int g = head->gate;
+        for (int r = 0; r < world; ++r) g |= (int)tie_region[r * tie_block_words(S) + S];
+        head->gate = g;
+    }
 }
 
 // ---- stage 3: selected, positive candidates -> entry list + per-row / per-column counts -------------
 __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
                                                    const SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
-                                                   const uint32_t* __restrict__ tie_idx, int F, int L, uint32_t cap,
+                                                   const uint32_t* __restrict__ tie_region, int S, Shard sd, int F, int L, uint32_t cap,
                                                    uint32_t* __restrict__ sel_idx, float* __restrict__ sel_val,
                                                    uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt,
                                                    float* __restrict__ threshold, float e, Head* __restrict__ head,
@@ -204,8 +231,6 @@ __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ 
     const SegState st = state[s];
     const uint32_t T = st.prefix;
     const bool rank_ties = need_rank(st);
-    const uint32_t nt = rank_ties ? ctl[s].tie_cnt : 0;
-    const uint32_t* tl = tie_idx + (size_t)s * TIECAP;
     const uint32_t n = ctl[s].cand_cnt;
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t i0 = blockIdx.x * per, i1 = min(n, i0 + per);
@@ -221,9 +246,14 @@ __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ 
         if (key > T) return true;
         if (key < T) return false;
         if (!rank_ties) return true;
-        const uint32_t me = ci[i];
+        const uint32_t me = global_index(ci[i], F, sd);
         uint32_t r = 0;
-        for (uint32_t j = 0; j < nt; ++j) r += tl[j] < me;
+        for (int q = 0; q < sd.world; ++q) {            // tied entries of every shard, by global index
+            const uint32_t* blk = tie_region + q * tie_block_words(S);
+            const uint32_t nt = min(blk[s], TIECAP);
+            const uint32_t* tl = blk + S + 1 + (size_t)s * TIECAP;
+            for (uint32_t j = 0; j < nt; ++j) r += tl[j] < me;
+        }
         return r < st.krem;
     };
     uint32_t cnt = 0;
@@ -285,33 +315,37 @@ __global__ void publish_gate_kernel(const Head* __restrict__ head, int32_t* __re
 struct LPlan {
     int S, RS, rows, ncols, rpb, NC;
     uint32_t Kseg, ns, rank, capS;
+    size_t tie_words;
     size_t off_ctl, off_state, off_ghist, off_tie, off_rowcnt, off_rowcur, off_colcnt, off_colcur, zero_end;
     size_t off_long, off_sample, off_ckey, off_cidx, off_sidx, off_sval, off_fbsel, off_fbbuild, total;
 };
 
-LPlan lplan(int B, int L, int F, int k, int mode) {
+// Kseg = k * (rows of a segment): the GLOBAL number of selected entries of a segment; a shard expects 1/world of it.
+LPlan lplan(int B, int L, int F, int k, int mode, int world, int exhaustive) {
     LPlan p;
     p.S = mode == 2 ? L : 1;
     p.RS = mode == 2 ? B : B * L;
     p.rows = B * L; p.ncols = L * F;
     const unsigned long long nseg = (unsigned long long)p.RS * F;
     const unsigned long long K = (unsigned long long)k * p.RS;
+    const unsigned long long Kloc = (K + world - 1) / world;
     p.Kseg = (uint32_t)K;
     p.ns = (uint32_t)(nseg < NS_MAX ? nseg : NS_MAX);
-    const double m = (double)p.ns * (double)K / (double)nseg;
+    const double m = (double)p.ns * (double)Kloc / (double)nseg;
     const double r = m + 8.0 * sqrt(m) + 32.0;
-    p.rank = r >= (double)p.ns ? p.ns : (uint32_t)r;
-    unsigned long long capS = 4ull * K + 65536ull;
-    if (capS > nseg) capS = nseg;
+    p.rank = (exhaustive || r >= (double)p.ns) ? p.ns : (uint32_t)r;
+    unsigned long long capS = 4ull * Kloc + 65536ull;
+    if (capS > nseg || exhaustive) capS = nseg;
     p.capS = (uint32_t)capS;
     p.rpb = 16; if (p.rpb > p.RS) p.rpb = p.RS;
     p.NC = (p.RS + p.rpb - 1) / p.rpb;
+    p.tie_words = (size_t)p.S + 1 + (size_t)p.S * TIECAP;
     size_t o = sizeof(Head);
     auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
     p.off_ctl = take((size_t)p.S * sizeof(SelCtl));
     p.off_state = take((size_t)p.S * sizeof(SegState));
-    p.off_ghist = take((size_t)p.S * NBIN * 4);
-    p.off_tie = take(mode == 0 ? 0 : (size_t)p.S * TIECAP * 4);
+    p.off_ghist = take((size_t)p.S * NBIN * 4 + (size_t)p.S * 4);          // histograms | per-segment candidate totals
+    p.off_tie = take(mode == 0 ? 0 : p.tie_words * 4 * world);
     p.off_rowcnt = take((size_t)p.rows * 4);
     p.off_rowcur = take((size_t)p.rows * 4);
     p.off_colcnt = take((size_t)p.ncols * 4);
@@ -329,18 +363,157 @@ LPlan lplan(int B, int L, int F, int k, int mode) {
         p.off_cidx = take((size_t)p.S * p.capS * 4);
         p.off_sidx = take((size_t)K * p.S * 4);
         p.off_sval = take((size_t)K * p.S * 4);
-        p.off_fbsel = take(clt_topk_segmented_workspace_bytes(B, L, F, mode == 2));
-        p.off_fbbuild = take(clt_sparse_build_workspace_bytes(B, L, F));
+        p.off_fbsel = take(world == 1 ? clt_topk_segmented_workspace_bytes(B, L, F, mode == 2) : 0);
+        p.off_fbbuild = take(world == 1 ? clt_sparse_build_workspace_bytes(B, L, F) : 0);
     }
     p.total = o;
     return p;
+}
+
+struct SelArgs {
+    const float* x; const uint8_t* col_mask; int B, L, F, k, mode; float* threshold; float ema_e; uint32_t cap;
+    uint32_t* row_start; int32_t* ent_col; float* ent_val; uint32_t* col_start; int32_t* csc_tok; float* csc_val;
+    int32_t* csc_ent; uint8_t* fired; uint32_t* total; int32_t* overflow; float* dense_scratch; int32_t* used_fallback;
+    void* ws; size_t wsb; hipStream_t st; Shard sd; int exhaustive;
+};
+
+// Stages (batch modes):  0 clear + sample -> lb            [sharded: MIN of lb over ranks]
+//                        1 filter, publish counts, hist 0  [sharded: SUM of {ghist, tot}]
+//                        2 check, find 0, hist 1           [SUM ghist]
+//                        3 find 1, hist 2                  [SUM ghist]
+//                        4 find 2, ties                    [ALL-GATHER tie blocks]
+//                        5 merge gate, emit, build lists (+ single-GPU exhaustive fallback, gated)
+// Rows mode runs entirely in stage 5 (no cross-row state).
+int run_stages(const SelArgs& a, int lo, int hi) {
+    const int B = a.B, L = a.L, F = a.F, k = a.k, mode = a.mode;
+    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 0 || mode > 2 || a.cap == 0 || a.sd.world < 1) return CLT_ERR_SHAPE;
+    if (k > (int)(a.sd.world > 1 ? a.sd.F_global : (uint32_t)F)) return CLT_ERR_K_GT_F;
+    const unsigned long long nall = (unsigned long long)B * L * (a.sd.world > 1 ? a.sd.F_global : (uint32_t)F);
+    if (nall >= 0xffffffffull || (unsigned long long)L * F >= 0x7fffffffull) return CLT_ERR_RANGE;
+    if (mode == 0 && (k > 2048 || a.sd.world > 1)) return CLT_ERR_RANGE;
+    if (mode != 0 && a.sd.world == 1 && !a.dense_scratch) return CLT_ERR_SHAPE;
+    hipStream_t st = a.st;
+    const int rows = B * L, ncols = L * F;
+    if (k == 0) {                                          // topk.py:86-87: nothing selected, no threshold update
+        if (hi < 5) return CLT_OK;
+        if (hipMemsetAsync(a.overflow, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (a.used_fallback && hipMemsetAsync(a.used_fallback, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(a.row_start, 0, (size_t)(rows + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(a.col_start, 0, (size_t)(ncols + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(a.fired, 0, (size_t)ncols, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        if (hipMemsetAsync(a.total, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+        return CLT_OK;
+    }
+    const int kk = mode == 0 ? k : k;                      // (k <= F checked above for one GPU; k may exceed a shard's F)
+    const LPlan p = lplan(B, L, F, kk, mode, a.sd.world, a.exhaustive);
+    if (!a.ws || a.wsb < p.total) return CLT_ERR_WORKSPACE;
+    char* w8 = (char*)a.ws;
+    Head* head = (Head*)w8;
+    SelCtl* ctl = (SelCtl*)(w8 + p.off_ctl);
+    SegState* state = (SegState*)(w8 + p.off_state);
+    uint32_t* ghist = (uint32_t*)(w8 + p.off_ghist);
+    uint32_t* tot = ghist + (size_t)p.S * NBIN;
+    uint32_t* tie_region = (uint32_t*)(w8 + p.off_tie);
+    uint32_t* row_cnt = (uint32_t*)(w8 + p.off_rowcnt);
+    uint32_t* row_cur = (uint32_t*)(w8 + p.off_rowcur);
+    uint32_t* col_cnt = (uint32_t*)(w8 + p.off_colcnt);
+    uint32_t* col_cur = (uint32_t*)(w8 + p.off_colcur);
+    int32_t* long_list = (int32_t*)(w8 + p.off_long);
+    uint32_t* sample = (uint32_t*)(w8 + p.off_sample);
+    uint32_t* ckey = (uint32_t*)(w8 + p.off_ckey);
+    uint32_t* cidx = (uint32_t*)(w8 + p.off_cidx);
+    uint32_t* sidx = (uint32_t*)(w8 + p.off_sidx);
+    float* sval = (float*)(w8 + p.off_sval);
+    const int32_t* gate = mode == 0 ? nullptr : &head->gate;
+    int nbk = (int)((p.capS + TPB * 16 - 1) / (TPB * 16)); if (nbk > 512) nbk = 512; if (nbk < 1) nbk = 1;
+    const dim3 cgrid(nbk, p.S);
+
+    for (int stage = lo; stage <= hi; ++stage) {
+        if (stage == 0) {
+            if (hipMemsetAsync(a.overflow, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            if (a.used_fallback && hipMemsetAsync(a.used_fallback, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            if (hipMemsetAsync(a.ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            if (mode == 0) continue;
+            if (p.rank < p.ns)
+                hipLaunchKernelGGL(sample_gather_kernel, dim3((p.ns + TPB - 1) / TPB, p.S), dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S,
+                                   p.RS, p.ns, sample);
+            hipLaunchKernelGGL(sample_kernel, dim3(p.S), dim3(TPB), 0, st, p.ns, p.rank, p.Kseg, sample, state, ctl);
+        } else if (mode == 0) {
+            if (stage != 5) continue;
+            int32_t* ci = (int32_t*)sidx;
+            const int rc = clt_internal_topk_rows(a.x, nullptr, rows, F, k, ci, sval, a.col_mask, L, row_cnt, col_cnt, st);
+            if (rc != CLT_OK) return rc;
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, ci, sval, k, F, L, rows, a.row_start, a.cap,
+                               a.ent_col, a.ent_val, a.overflow);
+        } else if (stage == 1) {
+            const dim3 fgrid(p.NC, p.S);
+            if (F % 4 == 0 && aligned16(a.x))
+                hipLaunchKernelGGL((filter_kernel<true>), fgrid, dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
+            else
+                hipLaunchKernelGGL((filter_kernel<false>), fgrid, dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
+            hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(64), 0, st, ctl, p.S, tot);
+            hipLaunchKernelGGL(cand_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, p.capS, ctl, state, ghist, 0);
+        } else if (stage == 2 || stage == 3) {
+            if (stage == 2) hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, st, ctl, tot, p.S, p.Kseg, p.capS, head);
+            hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, stage - 2, gate, 0);
+            hipLaunchKernelGGL(cand_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, p.capS, ctl, state, ghist, stage - 1);
+        } else if (stage == 4) {
+            hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
+            hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
+            hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head);
+        } else if (stage == 5) {
+            const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
+            const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
+            hipLaunchKernelGGL(merge_gate_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd.world, tie_region, head);
+            hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
+                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow);
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
+                               a.ent_col, a.ent_val);
+            hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
+                               (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
+            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
+                               long_list, &head->long_rows, gate, 0);
+        }
+        if (stage != 5) continue;
+        // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, a.col_start, (uint32_t*)nullptr, a.fired, gate, 0);
+        hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, rows, L, a.cap,
+                           a.col_start, col_cur, a.csc_tok, a.csc_val, a.csc_ent, gate, 0);
+        hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, a.col_start, ncols, a.csc_tok, a.csc_val,
+                           a.csc_ent, long_list, &head->long_cols, gate, 0);
+        hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, a.col_start, a.csc_tok, a.csc_val, a.csc_ent, long_list,
+                           &head->long_cols, gate, 0);
+        CLT_LAUNCH_CHECK();
+        if (mode != 0 && a.sd.world == 1) {                // exhaustive path, enqueued always, runs only when gated in
+            const float* src = a.x;
+            if (a.col_mask) {
+                hipLaunchKernelGGL(masked_copy_kernel, dim3(4096), dim3(TPB), 0, st, a.x, a.col_mask, (long)nall, (long)ncols,
+                                   a.dense_scratch, gate);
+                src = a.dense_scratch;
+            }
+            void* fbsel = w8 + p.off_fbsel;
+            void* fbbuild = w8 + p.off_fbbuild;
+            int rc = clt_internal_topk_segmented(src, a.dense_scratch, B, L, F, k, mode == 2, a.threshold, a.ema_e, fbsel,
+                                                 p.off_fbbuild - p.off_fbsel, st, gate);
+            if (rc != CLT_OK) return rc;
+            const size_t bb = clt_sparse_build_workspace_bytes(B, L, F);
+            if (hipMemsetAsync(fbbuild, 0, bb, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            rc = clt_internal_sparse_build(a.dense_scratch, B, L, F, a.cap, a.row_start, a.ent_col, a.ent_val, a.col_start,
+                                           a.csc_tok, a.csc_val, a.csc_ent, a.fired, a.total, a.overflow, fbbuild, bb, st, gate);
+            if (rc != CLT_OK) return rc;
+        }
+        if (mode != 0 && a.used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, a.used_fallback);
+    }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 }  // namespace
 
 extern "C" {
 size_t clt_select_lists_workspace_bytes(int B, int L, int F, int k, int mode) {
     if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 0 || mode > 2) return 0;
-    return lplan(B, L, F, k > F ? F : k, mode).total;
+    return lplan(B, L, F, k > F ? F : k, mode, 1, 0).total;
 }
 
 int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, int F, int k, int mode, float* threshold,
@@ -348,110 +521,41 @@ int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, 
                          uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent, uint8_t* fired,
                          uint32_t* total, int32_t* overflow, float* dense_scratch, int32_t* used_fallback, void* ws,
                          size_t wsb, void* stp) {
-    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 0 || mode > 2 || cap == 0) return CLT_ERR_SHAPE;
-    if (k > F) return CLT_ERR_K_GT_F;
-    const unsigned long long nall = (unsigned long long)B * L * F;
-    if (nall >= 0xffffffffull || (unsigned long long)L * F >= 0x7fffffffull) return CLT_ERR_RANGE;
-    if (mode == 0 && k > 2048) return CLT_ERR_RANGE;
-    if (mode != 0 && !dense_scratch) return CLT_ERR_SHAPE;
-    hipStream_t st = as_stream(stp);
-    const int rows = B * L, ncols = L * F;
-    if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
-    if (used_fallback && hipMemsetAsync(used_fallback, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
-    if (k == 0) {                                          // topk.py:86-87: nothing selected, no threshold update
-        if (hipMemsetAsync(row_start, 0, (size_t)(rows + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
-        if (hipMemsetAsync(col_start, 0, (size_t)(ncols + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
-        if (hipMemsetAsync(fired, 0, (size_t)ncols, st) != hipSuccess) return CLT_ERR_LAUNCH;
-        if (hipMemsetAsync(total, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
-        return CLT_OK;
-    }
-    const LPlan p = lplan(B, L, F, k, mode);
-    if (!ws || wsb < p.total) return CLT_ERR_WORKSPACE;
-    char* w8 = (char*)ws;
-    Head* head = (Head*)w8;
-    SelCtl* ctl = (SelCtl*)(w8 + p.off_ctl);
-    SegState* state = (SegState*)(w8 + p.off_state);
-    uint32_t* ghist = (uint32_t*)(w8 + p.off_ghist);
-    uint32_t* tie_idx = (uint32_t*)(w8 + p.off_tie);
-    uint32_t* row_cnt = (uint32_t*)(w8 + p.off_rowcnt);
-    uint32_t* row_cur = (uint32_t*)(w8 + p.off_rowcur);
-    uint32_t* col_cnt = (uint32_t*)(w8 + p.off_colcnt);
-    uint32_t* col_cur = (uint32_t*)(w8 + p.off_colcur);
-    int32_t* long_list = (int32_t*)(w8 + p.off_long);
-    if (hipMemsetAsync(ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
-    const int32_t* gate = nullptr;                         // rows mode has no probabilistic stage
+    SelArgs a{x, col_mask, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
+              csc_ent, fired, total, overflow, dense_scratch, used_fallback, ws, wsb, as_stream(stp), Shard{1, 0, 0u, (uint32_t)F}, 0};
+    return run_stages(a, 0, 5);
+}
 
-    if (mode == 0) {
-        int32_t* cidx = (int32_t*)(w8 + p.off_sidx);
-        float* cval = (float*)(w8 + p.off_sval);
-        const int rc = clt_internal_topk_rows(x, nullptr, rows, F, k, cidx, cval, col_mask, L, row_cnt, col_cnt, st);
-        if (rc != CLT_OK) return rc;
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 0);
-        hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, cidx, cval, k, F, L, rows, row_start, cap,
-                           ent_col, ent_val, overflow);
-    } else {
-        uint32_t* sample = (uint32_t*)(w8 + p.off_sample);
-        uint32_t* ckey = (uint32_t*)(w8 + p.off_ckey);
-        uint32_t* cidx = (uint32_t*)(w8 + p.off_cidx);
-        uint32_t* sidx = (uint32_t*)(w8 + p.off_sidx);
-        float* sval = (float*)(w8 + p.off_sval);
-        gate = &head->gate;
-        hipLaunchKernelGGL(sample_kernel, dim3(p.S), dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.ns, p.rank, p.Kseg, sample,
-                           state, ctl);
-        const dim3 fgrid(p.NC, p.S);
-        if (F % 4 == 0 && aligned16(x))
-            hipLaunchKernelGGL((filter_kernel<true>), fgrid, dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
-        else
-            hipLaunchKernelGGL((filter_kernel<false>), fgrid, dim3(TPB), 0, st, x, col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
-        hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, st, ctl, p.S, p.Kseg, p.capS, head);
-        int nbk = (int)((p.capS + TPB * 16 - 1) / (TPB * 16)); if (nbk > 512) nbk = 512; if (nbk < 1) nbk = 1;
-        const dim3 cgrid(nbk, p.S);
-        for (int pass = 0; pass < 3; ++pass) {
-            hipLaunchKernelGGL(cand_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, p.capS, ctl, state, ghist, pass, head);
-            hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, pass, gate, 0);
-        }
-        hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_idx, head);
-        hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, ctl, p.S, head);
-        const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
-        const uint32_t capsel = cap < kall ? cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
-        hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_idx, F, L, capsel, sidx, sval,
-                           row_cnt, col_cnt, threshold, ema_e, head, overflow);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 0);
-        hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, row_start, row_cur, ent_col,
-                           ent_val);
-        hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, row_start, rows, ent_col, ent_val,
-                           (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
-        hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, row_start, ent_col, ent_val, (int32_t*)nullptr, long_list,
-                           &head->long_rows, gate, 0);
-    }
-    // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, col_start, (uint32_t*)nullptr, fired, gate, 0);
-    hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap, col_start,
-                       col_cur, csc_tok, csc_val, csc_ent, gate, 0);
-    hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val, csc_ent,
-                       long_list, &head->long_cols, gate, 0);
-    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
-                       &head->long_cols, gate, 0);
-    CLT_LAUNCH_CHECK();
+size_t clt_select_lists_sharded_workspace_bytes(int B, int L, int F, int k, int mode, int world, int exhaustive) {
+    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 1 || mode > 2 || world < 1) return 0;
+    return lplan(B, L, F, k, mode, world, exhaustive).total;
+}
 
-    if (mode != 0) {                                       // exhaustive path, enqueued always, runs only when gated in
-        const float* src = x;
-        if (col_mask) {
-            hipLaunchKernelGGL(masked_copy_kernel, dim3(4096), dim3(TPB), 0, st, x, col_mask, (long)nall, (long)ncols, dense_scratch, gate);
-            src = dense_scratch;
-        }
-        void* fbsel = w8 + p.off_fbsel;
-        void* fbbuild = w8 + p.off_fbbuild;
-        int rc = clt_internal_topk_segmented(src, dense_scratch, B, L, F, k, mode == 2, threshold, ema_e, fbsel,
-                                             p.off_fbbuild - p.off_fbsel, st, gate);
-        if (rc != CLT_OK) return rc;
-        const size_t bb = clt_sparse_build_workspace_bytes(B, L, F);
-        if (hipMemsetAsync(fbbuild, 0, bb, st) != hipSuccess) return CLT_ERR_LAUNCH;
-        rc = clt_internal_sparse_build(dense_scratch, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
-                                       csc_ent, fired, total, overflow, fbbuild, bb, st, gate);
-        if (rc != CLT_OK) return rc;
-        if (used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, used_fallback);
+size_t clt_select_lists_exchange_info(int B, int L, int F, int k, int mode, int world, int exhaustive, int which) {
+    if (B <= 0 || L <= 0 || F <= 0 || k < 0 || mode < 1 || mode > 2 || world < 1) return 0;
+    const LPlan p = lplan(B, L, F, k, mode, world, exhaustive);
+    switch (which) {
+        case 0: return p.off_ctl;                          // SelCtl[S]: word 0 of each 16-byte record = lower-bound key
+        case 1: return p.off_ghist;                        // uint32 [S*2048 + S]: histograms | candidate totals
+        case 2: return (size_t)p.S * NBIN + p.S;           // ... its length in words
+        case 3: return p.off_tie;                          // uint32 [world][tie_words]
+        case 4: return p.tie_words;
+        case 5: return 0;                                  // Head: word 0 = gate
+        default: return 0;
     }
-    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, int exhaustive,
+                                 const float* x, const uint8_t* col_mask, int B, int L, int F, int k, int mode,
+                                 float* threshold, float ema_e, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
+                                 float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
+                                 uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback, void* ws, size_t wsb,
+                                 void* stp) {
+    if (stage_lo < 0 || stage_hi > 5 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1) return CLT_ERR_SHAPE;
+    if (f_off < 0 || f_off + F > F_global) return CLT_ERR_SHAPE;
+    SelArgs a{x, col_mask, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
+              csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, exhaustive};
+    return run_stages(a, stage_lo, stage_hi);
 }
 }  // extern "C"

@@ -193,6 +193,24 @@ int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, 
                          uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent, uint8_t* fired,
                          uint32_t* total, int32_t* overflow, float* dense_scratch, int32_t* used_fallback,
                          void* workspace, size_t ws_bytes, void* stream);
+/* Feature-sharded form of the batch modes (1, 2) for one process per GPU: this rank holds columns
+ * [f_off, f_off + F) of F_global features per layer; k counts per (b,l) row over ALL F_global features.  The
+ * selection runs as stages stage_lo..stage_hi with a collective (issued by the host, torch.distributed / RCCL)
+ * on a region of the workspace between stages:
+ *   after 0: MIN  over ranks of the lower-bound keys   (word 0 of each 16-byte record at exchange offset 0, S records)
+ *   after 1, 2, 3: SUM over ranks of the uint32 array at exchange offset 1 (length: info 2): histograms | counts
+ *   after 4: ALL-GATHER of the per-rank tie blocks (offset 3, info 4 words each; rank r's block is block r)
+ *   5: emit + list build; used_fallback[0] != 0 afterwards means the candidate set was insufficient on some rank
+ *      (nothing was emitted): the host re-runs all stages with exhaustive = 1 (every element is a candidate).
+ * Replaces the DTensor plumbing of model/parallel.py, which cannot shard TopK modules at all (parallel.py:268-274). */
+size_t clt_select_lists_sharded_workspace_bytes(int B, int L, int F, int k, int mode, int world, int exhaustive);
+size_t clt_select_lists_exchange_info(int B, int L, int F, int k, int mode, int world, int exhaustive, int which);
+int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, int exhaustive,
+                                 const float* x, const uint8_t* col_mask, int B, int L, int F, int k, int mode,
+                                 float* threshold, float ema_e, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
+                                 float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
+                                 uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback,
+                                 void* workspace, size_t ws_bytes, void* stream);
 /* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
  * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
  * Wptr: DEVICE array of L device pointers. */
