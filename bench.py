@@ -31,12 +31,14 @@ def synth_batch(B, L, d, device, seed=42):
     return torch.stack([x, y], dim=1).contiguous()
 
 
-def build(args, device):
+def build(args, device, rank=0, world=1):
+    """The module of this rank: with world > 1 the feature axis is sharded (crosslayer_transcoder_amd.parallel), every
+    rank constructs only its F/world features per layer (own seed) and the replicated pieces identically."""
     from crosslayer_transcoder_amd.model import BatchTopK, CrossLayerTranscoder, CrosslayerDecoder, Encoder, PerLayerTopK
     from crosslayer_transcoder_amd.model.clt_lightning import CrossLayerTranscoderModule, TopKCrossLayerTranscoderModule
     from crosslayer_transcoder_amd.model.standardize import DimensionwiseInputStandardizer, DimensionwiseOutputStandardizer
-    L, d, F = args.layers, args.d_acts, args.features
-    torch.manual_seed(42)
+    L, d, F = args.layers, args.d_acts, args.features // world
+    torch.manual_seed(42 + rank)
     with torch.device(device):
         model = CrossLayerTranscoder(BatchTopK(k=args.k, e=0.01), Encoder(d, F, L), CrosslayerDecoder(d, F, L),
                                      DimensionwiseInputStandardizer(L, d), DimensionwiseOutputStandardizer(L, d))
@@ -46,7 +48,13 @@ def build(args, device):
         else:
             mod = CrossLayerTranscoderModule(model=model, learning_rate=1e-4)
     mod.trainer.max_steps = 100_000
-    return mod.to(device)
+    mod = mod.to(device)
+    if world > 1:
+        from crosslayer_transcoder_amd.parallel import FeatureShard
+        with torch.no_grad():      # same init distribution as the full model (bounds depend on the GLOBAL feature count)
+            mod.model.encoder.W.mul_((F / args.features) ** 0.5)
+        mod.shard = FeatureShard(args.features)
+    return mod
 
 
 def cpu_baseline(args):
@@ -127,16 +135,22 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)           # (rehearsal: several ranks may share one GPU under CLT_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
+    backend = os.environ.get("CLT_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import crosslayer_transcoder_amd as cta
     cta.set_precision(args.precision)
-    mod = build(args, device)
+    mod = build(args, device, rank, world)
     opt = mod.configure_optimizers()
     batch = synth_batch(args.batch, args.layers, args.d_acts, device)
 
@@ -160,7 +174,7 @@ def main():
     dt = time.perf_counter() - t0
     timing, ops.TIMING = ops.TIMING, None
     if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ms = dt / args.steps * 1e3

@@ -41,11 +41,19 @@ def _select(nl, pre):
                               nl.e or 0.0)
 
 
-def _select_lists(nl, pre, col_mask=None):
+def _select_lists(nl, pre, col_mask=None, shard=None):
     """TopK-family training forward straight to the active-entry lists (no dense feature tensor).  `col_mask`
     (uint8 [L,F]) restricts the candidates to the masked-in features: where(mask, pre, -inf) (clt_lightning.py:544-545)."""
     Bn, L, F = pre.shape
-    assert nl.k <= F
+    assert nl.k <= (F if shard is None else shard.F_global)
+    if shard is not None:
+        if isinstance(nl, PerLayerTopK):
+            raise NotImplementedError("PerLayerTopK under feature sharding is not implemented (BatchTopK / "
+                                      "PerLayerBatchTopK, ReLU and JumpReLU are)")
+        if nl.k > 0 and nl.e is None:
+            raise TypeError("BatchTopK needs `e` (threshold EMA rate) for training")
+        mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
+        return ops.select_lists_sharded(pre, nl.k, mode, shard, nl.threshold if nl.k > 0 else None, nl.e or 0.0, col_mask)
     if isinstance(nl, PerLayerTopK):
         if nl.k > 2048:                         # compact-row buffer limit of the rows kernel: go through the dense result
             x = pre if col_mask is None else ops.mask_dead(pre, col_mask)
@@ -87,8 +95,9 @@ def _encoder_operand(enc):
 class _Decoder:
     """Dense decoder passes for either decoder class, on operands in the active precision."""
 
-    def __init__(self, dec):
+    def __init__(self, dec, shard=None):
         self.dec = dec
+        self.shard = shard
         self.clt = isinstance(dec, CrosslayerDecoder)
         self.L = dec.n_layers
         self.W32 = dec.weights()
@@ -103,8 +112,16 @@ class _Decoder:
     def names(self):
         return [f"decoder.W_{l}" for l in range(self.L)] if self.clt else ["decoder.W"]
 
+    def _bias(self):
+        """The (replicated) bias enters the all-reduced sum exactly once."""
+        return self.dec.b if self.shard is None or self.shard.rank == 0 else None
+
+    def _reduce(self, r):
+        return r if self.shard is None else self.shard.all_reduce_sum(r)
+
     def fwd(self, fo):
-        return ops.clt_decoder_fwd(fo, self.Wop, self.dec.b) if self.clt else ops.plt_decoder_fwd(fo, self.Wop[0], self.dec.b)
+        r = ops.clt_decoder_fwd(fo, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(fo, self.Wop[0], self._bias())
+        return self._reduce(r)
 
     def dgrad(self, go):
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
@@ -141,7 +158,7 @@ class _Decoder:
         return cached[1]
 
     def sparse_fwd(self, S):
-        return ops.sparse_decoder_fwd(S, self.pointer_table(), self.dec.b, self.dec.d_acts, self.clt)
+        return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt))
 
     def sparse_bwd(self, S, g, S2, g2, grads, fused):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
@@ -204,8 +221,11 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
 
     theta = None
     feat = S = None
+    shard = getattr(mod, "shard", None)
+    if shard is not None and shard.world == 1:
+        shard = None
     if sparse:
-        S = _select_lists(nl, pre)
+        S = _select_lists(nl, pre, shard=shard)
     elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
@@ -216,7 +236,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     else:
         raise NotImplementedError(f"fused step: unsupported nonlinearity {type(nl).__name__}")
 
-    D = _Decoder(dec)
+    D = _Decoder(dec, shard)
     N = Bn * L * d
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"
@@ -231,7 +251,9 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
     terms = {"mse": (loss_sum[0] / N).float()}
     dead, dead_cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
-    terms["dead_fraction"] = dead_cnt[0].float() / (L * F)
+    if shard is not None:                     # features are split over ranks: count over all shards
+        dead_cnt = shard.all_reduce_sum(dead_cnt.clone())
+    terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
     out = StepOutput(terms=terms, grads=grads, dead=dead, recons_norm=r, pre_actvs=pre)
     if feat is not None:
         out["features"] = feat
@@ -240,7 +262,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         S2 = g_aux = None
         if kind == "topk":
             aux = mod.topk_aux
-            S2 = _select_lists(aux, pre, dead)
+            S2 = _select_lists(aux, pre, dead, shard)
             aux_r = D.sparse_fwd(S2)
             aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
             terms["aux"] = (aux_sum[0] / N).float()
@@ -281,6 +303,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         dfeat = D.dgrad(go)
         sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                     mod.pre_actv_loss / (Bn * L))
+        if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
+            sums = shard.all_reduce_sum(sums.clone())
         D.wgrad(fo, go, grads)
         D.add_norm_grads(dn, sq, grads)
         grads["decoder.b"] = ops.column_sum(g)
@@ -288,7 +312,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             grads["nonlinearity.theta"] = dth
         terms["sparsity"] = (lam * sums[0] / Bn).float()
         terms["pre_actv"] = (mod.pre_actv_loss * sums[1] / (Bn * L)).float()
-        terms["weighted_features_mean"] = (sums[2] / (Bn * L * F)).float()
+        terms["weighted_features_mean"] = (sums[2] / (Bn * L * F * (shard.world if shard is not None else 1))).float()
         terms["sparsity_penalty"] = torch.tensor(lam)
         loss = terms["mse"] + terms["sparsity"] + terms["pre_actv"]
     else:

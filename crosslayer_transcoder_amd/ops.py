@@ -493,6 +493,59 @@ def select_lists(x: torch.Tensor, k: int, mode: int, threshold: Optional[torch.T
     return s
 
 
+def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: Optional[torch.Tensor] = None, e: float = 0.0,
+                         col_mask: Optional[torch.Tensor] = None, cap: Optional[int] = None) -> SparseLists:
+    """Feature-sharded BatchTopK / PerLayerBatchTopK selection (x = this rank's [B, L, F_local] pre-activations,
+    k per (b, l) row over all shard.F_global features).  Lists are rank-local.  One host read of the outcome flag
+    per call; if the sampled candidate set was insufficient on any rank, all ranks re-run exhaustively."""
+    from .parallel import run_sharded_selection
+    _chk(x)
+    if mode not in (SELECT_BATCH, SELECT_LAYER):
+        raise NotImplementedError("feature-sharded selection covers BatchTopK / PerLayerBatchTopK (per-row TopK across "
+                                  "shards needs a per-row candidate exchange: not implemented)")
+    Bn, L, F = x.shape
+    assert F == shard.F_local
+    if k > shard.F_global:
+        raise AssertionError("k must be <= d_features")
+    kglob = max(1, k * Bn * L)
+    if cap is None:
+        cap = min(kglob, 2 * kglob // shard.world + 65536)
+    S = L if mode == SELECT_LAYER else 1
+    fb = torch.zeros(1, dtype=torch.int32, device=x.device)
+    if col_mask is not None:
+        _chk(col_mask, torch.uint8)
+    if threshold is not None:
+        _chk(threshold)
+    for exhaustive in (0, 1):
+        s = _empty_lists(Bn, L, F, cap, x.device)
+        dims = (Bn, L, F, k, mode, shard.world, exhaustive)
+        nb = lib.clt_select_lists_sharded_workspace_bytes(*dims)
+        ws = workspace(nb, x.device)
+        off = [lib.clt_select_lists_exchange_info(*dims, w) for w in range(5)]
+        i32 = lambda o, n: ws[o:o + 4 * n].view(torch.int32)  # noqa: E731
+        exchange = {"lb": i32(off[0], 4 * S).view(S, 4), "hist": i32(off[1], off[2]),
+                    "ties": i32(off[3], off[4] * shard.world).view(shard.world, off[4])}
+
+        def stages(lo, hi):
+            call("clt_select_lists_sharded_f32", lo, hi, shard.world, shard.rank, shard.f_off, shard.F_global, exhaustive,
+                 x.data_ptr(), col_mask.data_ptr() if col_mask is not None else None, Bn, L, F, k, mode,
+                 threshold.data_ptr() if threshold is not None else None, float(e or 0.0), s.cap, s.row_start.data_ptr(),
+                 s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
+                 s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
+                 fb.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+
+        if k == 0:
+            stages(0, 5)
+            break
+        run_sharded_selection(stages, shard, S, exchange)
+        if int(fb) == 0:                           # the step's only host read: did every rank have enough candidates?
+            break
+    else:
+        raise NotImplementedError("BatchTopK under feature sharding: more than 4096 values tied at the threshold on one shard")
+    s.used_fallback = torch.full((1,), exhaustive, dtype=torch.int32, device=x.device)
+    return s
+
+
 def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
     """Device array of device pointers (one small H2D copy; cache it while the storages are stable)."""
     return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(tensors[0].device)

@@ -1,0 +1,117 @@
+"""Feature-axis sharding of the training step over one process per GPU (replaces the DTensor tensor-parallel
+plumbing of reference model/parallel.py:157-339, which shards the same axis: encoder W `Shard(-1)` :186-192,
+theta `Shard(-1)` :235-255, decoder W_i `Shard(-2)` :303-310, decoder output Partial->Replicate :313-326).
+
+Rank r of `world` owns features [f_off, f_off + F_local) of every layer: its rows of the encoder weight, of every
+decoder matrix, of theta / last_active and of the Adam state.  The batch, decoder bias and standardizer buffers are
+replicated.  Per step there is ONE exchange of activations — all-reduce(sum) of the partial reconstruction
+[B, L, d] (a second one for the TopK-aux pass) — plus the few-KB exchanges of the global BatchTopK selection
+(lower bound MIN, three radix-histogram SUMs, tie lists ALL-GATHER) and one packed scalar all-reduce.  Backward and
+Adam are rank-local: g = dL/drecons is replicated, weight shards are disjoint.
+
+Collectives go through torch.distributed (backend "nccl" = RCCL over xGMI).  With the gloo backend (CPU tests, or
+several ranks sharing one GPU) device tensors are staged through host memory.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FeatureShard:
+    def __init__(self, F_global: int, group=None, rank: Optional[int] = None, world: Optional[int] = None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        if F_global % self.world:
+            raise ValueError(f"d_features ({F_global}) must be divisible by the number of shards ({self.world})")
+        self.F_global = F_global
+        self.F_local = F_global // self.world
+        self.f_off = self.rank * self.F_local
+        self._host_staged = dist.get_backend(group) == "gloo"
+
+    # ---- collectives (in place) -----------------------------------------------------------------
+    def _run(self, fn, t: torch.Tensor):
+        if self._host_staged and t.is_cuda:
+            h = t.cpu()
+            fn(h)
+            t.copy_(h)
+        else:
+            fn(t)
+        return t
+
+    def all_reduce_sum(self, t):
+        return self._run(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group), t)
+
+    def all_reduce_min(self, t):
+        return self._run(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.group), t)
+
+    def all_gather_blocks(self, region: torch.Tensor):
+        """region: [world, n]; block `rank` holds this rank's data; fills every block."""
+        mine = region[self.rank].clone().reshape(-1)
+        if self._host_staged and region.is_cuda:
+            h = torch.empty(region.numel(), dtype=region.dtype)
+            dist.all_gather_into_tensor(h, mine.cpu(), group=self.group)
+            region.copy_(h.view(region.shape))
+        else:
+            assert region.is_contiguous()
+            dist.all_gather_into_tensor(region.view(-1), mine, group=self.group)
+        return region
+
+    def slice_features(self, t: torch.Tensor, dim: int) -> torch.Tensor:
+        """This rank's slice of a full-size tensor along its feature axis."""
+        return t.narrow(dim, self.f_off, self.F_local)
+
+
+def run_sharded_selection(stages, shard: FeatureShard, S: int, exchange):
+    """Collective schedule of the sharded BatchTopK / PerLayerBatchTopK selection (include/clt_hip.h,
+    clt_select_lists_sharded_f32).  `stages(lo, hi)` runs the local kernels of stages lo..hi; `exchange` maps
+    "lb" -> int32 [S, 4] records (column 0 = lower-bound key), "hist" -> int32 [S*2048 + S], "ties" -> int32
+    [world, tie_words] views of the selection workspace."""
+    stages(0, 0)
+    lb = exchange["lb"]
+    keys = lb[:, 0].to(torch.int64) & 0xFFFFFFFF            # uint32 keys: order them as unsigned
+    shard.all_reduce_min(keys)
+    lb[:, 0] = (keys - (keys >= 2 ** 31).to(torch.int64) * 2 ** 32).to(torch.int32)      # back to the uint32 bit pattern
+    for st in (1, 2, 3):
+        stages(st, st)
+        shard.all_reduce_sum(exchange["hist"])
+    stages(4, 4)
+    shard.all_gather_blocks(exchange["ties"])
+    stages(5, 5)
+
+
+def shard_module(mod, shard: FeatureShard):
+    """Turn a full-size training module (identical on every rank, e.g. same seed or same checkpoint) into this
+    rank's shard IN PLACE: parameters and buffers with a feature axis keep only [f_off, f_off + F_local).
+    Afterwards `mod.shard` routes the step's exchange points through `shard` (engine.training_step)."""
+    import torch.nn as nn
+    model = mod.model
+    enc, dec, nl = model.encoder, model.decoder, model.nonlinearity
+    if enc.d_features != shard.F_global:
+        raise ValueError(f"module has d_features={enc.d_features}, shard expects {shard.F_global}")
+    f0, n = shard.f_off, shard.F_local
+    with torch.no_grad():
+        Wt = enc.Wt[:, f0:f0 + n].contiguous()                        # feature-major storage [L, F_local, d]
+        enc.W = nn.Parameter(Wt.permute(0, 2, 1))
+        enc.b = nn.Parameter(enc.b[:, f0:f0 + n].contiguous())
+        enc.d_features = n
+        if hasattr(dec, "W"):
+            dec.W = nn.Parameter(dec.W[:, f0:f0 + n].contiguous())
+        else:
+            for l in range(dec.n_layers):
+                setattr(dec, f"W_{l}", nn.Parameter(getattr(dec, f"W_{l}")[:, f0:f0 + n].contiguous()))
+        dec.d_features = n
+        if hasattr(nl, "theta"):
+            nl.theta = nn.Parameter(nl.theta[..., f0:f0 + n].contiguous())
+            if hasattr(nl, "d_features"):
+                nl.d_features = n
+        mod.last_active = mod.last_active[:, f0:f0 + n].contiguous()
+    for m in (enc, dec):
+        for attr in ("_bf16_shadow", "_wptr"):
+            if hasattr(m, attr):
+                delattr(m, attr)
+    mod.shard = shard
+    return mod

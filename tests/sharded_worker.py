@@ -1,0 +1,190 @@
+"""One rank of the feature-sharded parity run (launched by tests/test_sharded.py through torch.distributed.run).
+
+GPU mode: every rank builds the FULL golden-case module, keeps its feature shard (parallel.shard_module) and runs
+the fused training steps; losses, local gradients, selected features, buffers and the parameters after the Adam
+steps must equal the corresponding slices of the UNSHARDED reference golden vectors.  Ranks may share one GPU: the
+collectives then run over gloo with host staging.
+
+--sim mode (CPU only, no HIP): checks the collective schedule of the sharded selection
+(parallel.run_sharded_selection) with a torch restatement of the kernel stages' contract.
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FEATURE_AXIS = {"encoder.W": 2, "encoder.b": 1, "nonlinearity.theta": 2, "decoder.W": 1}
+
+
+def feature_axis(name):
+    if name.startswith("decoder.W_"):
+        return 1
+    return FEATURE_AXIS.get(name)
+
+
+def gpu_case(name, fuse_adam):
+    from crosslayer_transcoder_amd.parallel import FeatureShard, shard_module
+    from tests.build_cases import build_module
+    from tests.conftest import load_golden
+    from tests.golden_cases import assert_close
+    case = load_golden(name)
+    mod = build_module(case, "cuda:0")
+    F = case["cfg"]["d_features"]
+    shard = FeatureShard(F)
+    shard_module(mod, shard)
+    conf = mod.configure_optimizers()
+    opt, sched = (conf["optimizer"], conf["lr_scheduler"]["scheduler"]) if isinstance(conf, dict) else (conf, None)
+    sl = lambda t, ax: t if ax is None else t.narrow(ax, shard.f_off, shard.F_local)  # noqa: E731
+    params = dict(mod.model.named_parameters())
+    for t, rec in enumerate(case["steps"]):
+        loss = mod.fused_train_step(case["batches"][t].cuda(), t, opt, sched, fuse_adam=fuse_adam)
+        assert_close(loss, rec["loss"], 2e-5, 1e-7, f"{name} loss step {t}")
+        out = mod.last_step
+        if t == 0:
+            feat = out["features"].cpu()
+            want = sl(rec["features"], 2)
+            assert torch.equal(feat > 0, want > 0), f"{name}: active set differs on rank {shard.rank}"
+            assert_close(feat, want, 1e-5, 1e-6, "features")
+            assert_close(out["recons_norm"], rec["recons_norm"], 1e-5, 2e-6, "recons_norm")
+            for k, g in out["grads"].items():
+                gref = sl(rec["grads"][k], feature_axis(k))
+                assert_close(g.reshape(gref.shape), gref, 1e-4, 2e-6 * float(rec["grads"][k].abs().max()) + 1e-12, f"grad {k}")
+        assert torch.equal(mod.last_active.cpu(), sl(rec["last_active"], 1)), f"last_active {t}"
+        assert_close(out["terms"]["dead_fraction"], rec["logged"]["metrics/dead_features"], 1e-6, 1e-7, "dead")
+        if "training/sparsity_loss" in rec["logged"]:
+            assert_close(out["terms"]["sparsity"], rec["logged"]["training/sparsity_loss"], 5e-5, 1e-8, "sparsity")
+            assert_close(out["terms"]["pre_actv"], rec["logged"]["training/pre_actv_loss"], 5e-5, 1e-10, "pre_actv")
+        if "threshold" in rec:
+            assert_close(mod.model.nonlinearity.threshold, rec["threshold"], 1e-5, 1e-7, "threshold")
+    lr = case["opt"]["lr"]
+    for k, p in params.items():
+        assert_close(p, sl(case["final_params"][k], feature_axis(k)), 1e-4, 0.3 * lr, f"{name} final {k}")
+    # replicated parameters stay bit-identical across ranks
+    b = mod.model.decoder.b.detach().clone()
+    ref = b.clone()
+    shard.all_reduce_min(ref)
+    assert torch.equal(b, ref), "decoder.b diverged between ranks"
+
+
+def sim_selection(rank, world):
+    """torch restatement of the stage contract of clt_select_lists_sharded_f32 on one shard."""
+    from crosslayer_transcoder_amd.parallel import FeatureShard, run_sharded_selection
+    from oracle import clt_oracle as O
+    NBIN, TIECAP = 2048, 4096
+    SHIFT, BITS = (21, 10, 0), (11, 11, 10)
+
+    def key_of(x):
+        u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        u = torch.where(u == 0x80000000, torch.zeros_like(u), u)
+        return torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u | 0x80000000)
+
+    for trial, (B, L, F, k, ties) in enumerate([(6, 3, 16, 2, False), (5, 2, 24, 3, True), (4, 1, 8, 8, False)]):
+        g = torch.Generator().manual_seed(100 + trial)
+        x = torch.randn(B, L, F, generator=g)
+        if ties:
+            x = torch.randint(0, 4, (B, L, F), generator=g).float() - 0.5
+        shard = FeatureShard(F, rank=rank, world=world)
+        xl = x[:, :, shard.f_off:shard.f_off + shard.F_local].contiguous()
+        Fl = shard.F_local
+        K = k * B * L
+        keys = key_of(xl).reshape(-1)
+        gidx = (torch.arange(B * L).repeat_interleave(Fl) * F + shard.f_off + torch.arange(Fl).repeat(B * L))
+        tw = 1 + 1 + TIECAP
+        ex = {"lb": torch.zeros(1, 4, dtype=torch.int32), "hist": torch.zeros(NBIN + 1, dtype=torch.int32),
+              "ties": torch.zeros(world, tw, dtype=torch.int32)}
+        st = {"prefix": 0, "mask": 0, "krem": K, "eq": 0}
+
+        def hist(p):
+            sel = keys[(keys & st["mask"]) == st["prefix"]]
+            ex["hist"][:NBIN] += torch.bincount((sel >> SHIFT[p]) & ((1 << BITS[p]) - 1), minlength=NBIN).to(torch.int32)
+
+        def find(p):
+            h = ex["hist"][:NBIN].to(torch.int64)
+            cum = 0
+            for b in range((1 << BITS[p]) - 1, -1, -1):
+                if cum + int(h[b]) >= st["krem"]:
+                    st["prefix"] |= b << SHIFT[p]
+                    st["mask"] |= ((1 << BITS[p]) - 1) << SHIFT[p]
+                    st["krem"] -= cum
+                    st["eq"] = int(h[b])
+                    break
+                cum += int(h[b])
+            ex["hist"][:NBIN] = 0
+
+        result = {}
+
+        def stages(lo, hi):
+            for s in range(lo, hi + 1):
+                if s == 0:
+                    lbk = int(keys.min()) if rank == 0 else int(keys.sort().values[len(keys) // 3])   # ranks disagree on purpose
+                    ex["lb"][0, 0] = lbk - (1 << 32) if lbk >= (1 << 31) else lbk
+                elif s == 1:
+                    lb = int(ex["lb"][0, 0]) & 0xFFFFFFFF
+                    assert lb == int(torch.tensor(lb)), "lb"
+                    st["cand"] = keys >= lb
+                    ex["hist"][NBIN] = int(st["cand"].sum())
+                    st["all_keys"] = keys
+                    keys_c = keys[st["cand"]]
+                    st["ck"], st["ci"] = keys_c, gidx[st["cand"]]
+                    sel = st["ck"]
+                    ex["hist"][:NBIN] += torch.bincount((sel >> SHIFT[0]) & 2047, minlength=NBIN).to(torch.int32)
+                elif s in (2, 3):
+                    if s == 2:
+                        assert int(ex["hist"][NBIN]) >= K, "global candidate count"
+                    find(s - 2)
+                    sel = st["ck"][(st["ck"] & st["mask"]) == st["prefix"]]
+                    ex["hist"][:NBIN] += torch.bincount((sel >> SHIFT[s - 1]) & ((1 << BITS[s - 1]) - 1), minlength=NBIN).to(torch.int32)
+                elif s == 4:
+                    find(2)
+                    T = st["prefix"]
+                    tied = st["ci"][st["ck"] == T]
+                    blk = ex["ties"][rank]
+                    blk[0] = len(tied)
+                    blk[2:2 + len(tied)] = tied.to(torch.int32)
+                elif s == 5:
+                    T = st["prefix"]
+                    allt = torch.cat([ex["ties"][r, 2:2 + int(ex["ties"][r, 0])] for r in range(world)]).to(torch.int64)
+                    need_rank = st["eq"] != st["krem"]
+                    take = st["ck"] > T
+                    eq = st["ck"] == T
+                    if need_rank:
+                        ranks = (allt[None, :] < st["ci"][eq][:, None]).sum(1)
+                        take[eq.nonzero().flatten()] = ranks < st["krem"]
+                    else:
+                        take |= eq
+                    result["idx"] = st["ci"][take]
+
+        run_sharded_selection(stages, shard, 1, ex)
+        ref, ridx, _ = O.batch_topk_fwd(x, k)
+        mine = set(int(i) for i in result["idx"])
+        want = set(int(i) for i in ridx if shard.f_off <= int(i) % F < shard.f_off + Fl)
+        assert mine == want, f"trial {trial} rank {rank}: sharded selection differs from the oracle"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sim", action="store_true")
+    ap.add_argument("--cases", default="batchtopk_clt_base,relu_clt_base,dbg_jumprelu_clt,jumprelu_plt_notanh")
+    args = ap.parse_args()
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    try:
+        if args.sim:
+            sim_selection(rank, world)
+        else:
+            torch.cuda.set_device(0)
+            for name in args.cases.split(","):
+                for fuse in (False, True):
+                    gpu_case(name, fuse)
+        print(f"rank {rank}: ok", flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+"""Feature-sharded (multi-process) path: world_size-2 runs over gloo."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(extra, nproc=2, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", "29513", os.path.join(ROOT, "tests", "sharded_worker.py")] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    assert p.stdout.count(": ok") == nproc
+
+
+def test_sharded_selection_schedule_gloo_cpu():
+    """Collective schedule of the sharded BatchTopK selection (lower-bound MIN, histogram SUMs, tie gather, global
+    tie order) against the oracle, two CPU ranks."""
+    _launch(["--sim"])
+
+
+@pytest.mark.gpu
+def test_sharded_training_matches_reference_two_ranks():
+    """Two ranks (sharing the GPU, gloo + host staging) each hold half of the features; every step equals the
+    unsharded reference golden vectors slice by slice."""
+    _launch([])
