@@ -34,15 +34,24 @@ def synth_batch(B, L, d, device, seed=42):
 def build(args, device, rank=0, world=1):
     """The module of this rank: with world > 1 the feature axis is sharded (crosslayer_transcoder_amd.parallel), every
     rank constructs only its F/world features per layer (own seed) and the replicated pieces identically."""
-    from crosslayer_transcoder_amd.model import BatchTopK, CrossLayerTranscoder, CrosslayerDecoder, Encoder, PerLayerTopK
-    from crosslayer_transcoder_amd.model.clt_lightning import CrossLayerTranscoderModule, TopKCrossLayerTranscoderModule
+    from crosslayer_transcoder_amd.model import (BatchTopK, CrossLayerTranscoder, CrosslayerDecoder, Decoder, Encoder, JumpReLU,
+                                                 PerLayerTopK, ReLU)
+    from crosslayer_transcoder_amd.model.clt_lightning import (CrossLayerTranscoderModule, JumpReLUCrossLayerTranscoderModule,
+                                                               TopKCrossLayerTranscoderModule)
     from crosslayer_transcoder_amd.model.standardize import DimensionwiseInputStandardizer, DimensionwiseOutputStandardizer
     L, d, F = args.layers, args.d_acts, args.features // world
     torch.manual_seed(42 + rank)
     with torch.device(device):
-        model = CrossLayerTranscoder(BatchTopK(k=args.k, e=0.01), Encoder(d, F, L), CrosslayerDecoder(d, F, L),
-                                     DimensionwiseInputStandardizer(L, d), DimensionwiseOutputStandardizer(L, d))
-        if args.aux:
+        nl = {"batchtopk": lambda: BatchTopK(k=args.k, e=0.01), "topk": lambda: PerLayerTopK(k=args.k), "relu": ReLU,
+              "jumprelu": lambda: JumpReLU(theta=0.03, bandwidth=0.01, n_layers=L, d_features=F)}[args.nonlinearity]()
+        dec = (CrosslayerDecoder if args.decoder == "clt" else Decoder)(d, F, L)
+        model = CrossLayerTranscoder(nl, Encoder(d, F, L), dec, DimensionwiseInputStandardizer(L, d),
+                                     DimensionwiseOutputStandardizer(L, d))
+        if args.nonlinearity == "jumprelu":
+            mod = JumpReLUCrossLayerTranscoderModule(model=model, learning_rate=1e-4, lambda_sparsity=7e-4, c_sparsity=1.0,
+                                                     use_tanh=True, pre_actv_loss=1e-6)
+            mod.global_step = 50_000               # global_step / max_steps = 0.5 (BASELINE.md §3)
+        elif args.aux:
             mod = TopKCrossLayerTranscoderModule(model=model, topk_aux=PerLayerTopK(k=512), learning_rate=1e-4,
                                                  tokens_till_dead=args.batch * 3)
         else:
@@ -95,8 +104,16 @@ def roofline(timing, mod, args):
     `achieved` = sum of those bytes over the timed launches / sum of their HIP-event durations."""
     ev = timing.get("row_pass", [])
     lists = mod.last_step.get("lists")
-    if not ev or lists is None:
-        return None
+    if not ev or lists is None:            # dense regime: the MFMA GEMMs dominate
+        gv = timing.get("gemm", [])
+        if not gv:
+            return None
+        flops = sum(p for _, _, p in gv)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gv)
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / BF16_PEAK_TFLOPS, "traffic": None, "launches": len(gv), "avg_launch_us": ms * 1e3 / len(gv),
+                "gemm_ms_per_step": ms / args.steps}
     col_start = lists.col_start.cpu().long()
     bf16 = args.precision.startswith("bf16")
     nbytes = ms = 0.0
@@ -127,6 +144,8 @@ def main():
     ap.add_argument("--d-acts", type=int, default=768)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--aux", action="store_true", help="TopK module with the k_aux=512 dead-feature loss")
+    ap.add_argument("--nonlinearity", default="batchtopk", choices=["batchtopk", "topk", "relu", "jumprelu"])
+    ap.add_argument("--decoder", default="clt", choices=["clt", "plt"])
     ap.add_argument("--precision", default="bf16-mixed")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,7 +205,9 @@ def main():
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
-        "config": {"workload": f"gpt2-small CLT BatchTopK(k={args.k}) L={L} d={d} F={F}/layer B={args.batch}"
+        "config": {"workload": f"gpt2-small {args.decoder.upper()} {args.nonlinearity}"
+                               + (f"(k={args.k})" if args.nonlinearity in ("batchtopk", "topk") else "")
+                               + f" L={L} d={d} F={F}/layer B={args.batch}"
                                + (" +aux(k=512)" if args.aux else ""),
                    "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
                    "loss": float(mod.last_step["loss"])},

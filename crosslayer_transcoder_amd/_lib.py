@@ -24,6 +24,7 @@ SIGNATURES = {
     "clt_destandardize_f32": (I, [P, P, P, I, I, P, P]),
     "clt_gemm_f32": (I, [P, P, P, I, I, I, L, L, L, I, I, I, L, L, L, P, L, I, P]),
     "clt_gemm_bf16": (I, [P, P, P, I, I, I, L, L, L, I, I, I, L, L, L, P, L, I, P]),
+    "clt_sum_slabs_f32": (I, [P, I, L, I, I, L, P, P, P]),
     "clt_cast_bf16": (I, [P, P, L, P]),
     "clt_cast_transpose_bf16": (I, [P, L, P, L, I, I, I, L, L, P]),
     "clt_relu_fwd_f32": (I, [P, P, L, P]),

@@ -304,6 +304,18 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
         if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = f32_to_bf16(tile[tx][c]);
 }
 
+// out[r*ld_out + j] = bias[j] + sum_s slabs[s*slab_stride + r*n + j]   (split-K partial results of the dense
+// cross-layer decoder: one [rows][n] slab per source layer, summed in source-layer order)
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, long total, int n, long ld_out,
+                                 const float* __restrict__ bias, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / n; const int j = (int)(i - r * n);
+        float acc = 0.0f;
+        for (int s = 0; s < nslab; ++s) acc += slabs[(long)s * slab_stride + i];
+        out[r * ld_out + j] = acc + (bias ? bias[j] : 0.0f);
+    }
+}
+
 // ---- K13 --------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n4, long n, float lr, float omb1, float b2, float omb2, float eps, float wd, int adamw,
@@ -489,6 +501,14 @@ int clt_cast_transpose_bf16(const float* in, long ldi, uint16_t* out, long ldo, 
     if (rows <= 0 || cols <= 0 || batch <= 0 || ldi < cols || ldo < rows) return CLT_ERR_SHAPE;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(TPB), 0, as_stream(st),
                        in, ldi, out, ldo, rows, cols, s_in, s_out);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_sum_slabs_f32(const float* slabs, int nslab, long slab_stride, int rows, int n, long ld_out, const float* bias,
+                      float* out, void* st) {
+    if (nslab <= 0 || rows <= 0 || n <= 0 || ld_out < n || slab_stride < (long)rows * n) return CLT_ERR_SHAPE;
+    const long total = (long)rows * n;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks_for(total, TPB)), dim3(TPB), 0, as_stream(st), slabs, nslab, slab_stride, total,
+                       n, ld_out, bias, out);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, double wd,

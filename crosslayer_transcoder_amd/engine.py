@@ -93,7 +93,10 @@ def _encoder_operand(enc):
 
 
 class _Decoder:
-    """Dense decoder passes for either decoder class, on operands in the active precision."""
+    """Decoder passes for either decoder class.  Dense passes take fp32 tensors and form their GEMM operands in
+    the active precision: fp32 -> the exact-fp32 MFMA kernel on the natural layouts; bf16 -> every contraction in
+    the k-contiguous "NT" form of the glds MFMA kernel, with transposed bf16 copies where the natural layout has
+    the contraction index outermost (decoder forward: weights^T; weight gradients: features^T and g^T)."""
 
     def __init__(self, dec, shard=None):
         self.dec = dec
@@ -101,13 +104,21 @@ class _Decoder:
         self.clt = isinstance(dec, CrosslayerDecoder)
         self.L = dec.n_layers
         self.W32 = dec.weights()
-        self._Wop = None
+        self.bf16 = get_precision() == "bf16"
+        self._Wop = self._WT = None
 
     @property
     def Wop(self):
         if self._Wop is None:
             self._Wop = [_op(w) for w in self.W32]
         return self._Wop
+
+    @property
+    def WT(self):
+        """bf16 [n, d, F] transposed copies of the decoder matrices (forward B operand, k = feature contiguous)."""
+        if self._WT is None:
+            self._WT = [ops.cast_transpose_bf16(w.contiguous()) for w in self.W32]
+        return self._WT
 
     def names(self):
         return [f"decoder.W_{l}" for l in range(self.L)] if self.clt else ["decoder.W"]
@@ -119,21 +130,42 @@ class _Decoder:
     def _reduce(self, r):
         return r if self.shard is None else self.shard.all_reduce_sum(r)
 
-    def fwd(self, fo):
-        r = ops.clt_decoder_fwd(fo, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(fo, self.Wop[0], self._bias())
+    def fwd(self, feat):
+        if self.bf16:
+            fo = ops.cast_bf16(feat)
+            r = ops.clt_decoder_fwd_t(fo, self.WT, self._bias()) if self.clt else ops.plt_decoder_fwd_t(fo, self.WT[0], self._bias())
+        else:
+            r = ops.clt_decoder_fwd(feat, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(feat, self.Wop[0], self._bias())
         return self._reduce(r)
 
-    def dgrad(self, go):
+    def dgrad(self, g):
+        go = _op(g)
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
 
-    def wgrad(self, fo, go, grads: Dict[str, torch.Tensor]):
-        """grads[name] (+)= wgrad; accumulates when the entry already exists."""
+    def wgrad(self, feat, g, grads: Dict[str, torch.Tensor]):
+        """grads[name] (+)= feat^T @ g; accumulates when the entry already exists."""
+        Bn, L, F = feat.shape
+        d = g.shape[2]
+        if self.bf16:
+            fT = ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
+            gT = ops.transpose_cast_2d(g).view(L, d, Bn)             # [L, d, B]
+            if self.clt:
+                for l in range(L):
+                    k = f"decoder.W_{l}"
+                    acc = k in grads
+                    out = grads[k] if acc else torch.empty(l + 1, F, d, dtype=torch.float32, device=feat.device)
+                    grads[k] = ops.wgrad_t(fT, gT[l], out, l + 1, F * Bn, 0, acc)
+            else:
+                acc = "decoder.W" in grads
+                out = grads["decoder.W"] if acc else torch.empty(L, F, d, dtype=torch.float32, device=feat.device)
+                grads["decoder.W"] = ops.wgrad_t(fT, gT, out, L, F * Bn, d * Bn, acc)
+            return
         if self.clt:
             for l in range(self.L):
                 k = f"decoder.W_{l}"
-                grads[k] = ops.clt_decoder_wgrad(fo, go, l, grads.get(k), accumulate=k in grads)
+                grads[k] = ops.clt_decoder_wgrad(feat, g, l, grads.get(k), accumulate=k in grads)
         else:
-            grads["decoder.W"] = ops.plt_decoder_wgrad(fo, go, grads.get("decoder.W"), accumulate="decoder.W" in grads)
+            grads["decoder.W"] = ops.plt_decoder_wgrad(feat, g, grads.get("decoder.W"), accumulate="decoder.W" in grads)
 
     def sqnorms(self):
         F = self.dec.d_features
@@ -215,7 +247,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if sparse and not (topk_family and kind in ("base", "topk")):
         raise NotImplementedError("the sparse regime covers TopK-family sparsifiers with the base / TopK-aux losses")
 
-    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, sparse or not bf16, bf16)
+    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, True, bf16)
     xo = xs16 if bf16 else xs32
     pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
 
@@ -245,8 +277,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         r = D.sparse_fwd(S)
         fired = S.fired
     else:
-        fo = _op(feat)
-        r = D.fwd(fo)
+        r = D.fwd(feat)
         fired = ops.column_any_positive(feat)
     loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
     terms = {"mse": (loss_sum[0] / N).float()}
@@ -299,13 +330,12 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         th = theta if theta is not None else torch.zeros(1, L, F, device=pre.device)
         bw = nl._bandwidth if theta is not None else 1.0
         sq = D.sqnorms()
-        go = _op(g)
-        dfeat = D.dgrad(go)
+        dfeat = D.dgrad(g)
         sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                     mod.pre_actv_loss / (Bn * L))
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
-        D.wgrad(fo, go, grads)
+        D.wgrad(feat, g, grads)
         D.add_norm_grads(dn, sq, grads)
         grads["decoder.b"] = ops.column_sum(g)
         if theta is not None:
@@ -320,20 +350,17 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             aux = mod.topk_aux
             dead_pre = ops.mask_dead(pre, dead)
             dead_feat = _select(aux, dead_pre)
-            dfo = _op(dead_feat)
-            aux_r = D.fwd(dfo)
+            aux_r = D.fwd(dead_feat)
             aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
             terms["aux"] = (aux_sum[0] / N).float()
             loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
-            gao = _op(g_aux)
-            D.wgrad(dfo, gao, grads)
+            D.wgrad(dead_feat, g_aux, grads)
             grads["decoder.b"] = ops.column_sum(g_aux)
         else:
             loss = terms["mse"]
-        go = _op(g)
-        D.wgrad(fo, go, grads)
+        D.wgrad(feat, g, grads)
         grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
-        dfeat = D.dgrad(go)
+        dfeat = D.dgrad(g)
         if theta is not None:
             dpre, grads["nonlinearity.theta"] = ops.jumprelu_bwd(pre, theta, nl._bandwidth, dfeat)
         elif isinstance(nl, ReLU):
@@ -341,9 +368,14 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         else:
             dpre = ops.mask_positive(feat, dfeat)
         if kind == "topk":
-            ops.mask_positive(dead_feat, D.dgrad(gao), out=dpre, accumulate=True)   # aux path reaches dead entries only
+            ops.mask_positive(dead_feat, D.dgrad(g_aux), out=dpre, accumulate=True)   # aux path reaches dead entries only
 
-    grads["encoder.W"] = ops.encoder_wgrad(xo, _op(dpre)).permute(0, 2, 1)
+    if bf16:       # dWt[l] [F, d] = dpre[:, l]^T @ xs[:, l], contraction over tokens: both operands token-minor
+        dWt = torch.empty(L, F, d, dtype=torch.float32, device=pre.device)
+        ops.wgrad_t(ops.transpose_cast_2d(dpre).view(L, F, Bn), ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt, L, F * Bn, d * Bn)
+        grads["encoder.W"] = dWt.permute(0, 2, 1)
+    else:
+        grads["encoder.W"] = ops.encoder_wgrad(xo, dpre).permute(0, 2, 1)
     grads["encoder.b"] = ops.column_sum(dpre)
     terms["loss"] = loss
     out["loss"] = loss

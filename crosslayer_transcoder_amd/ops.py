@@ -94,7 +94,7 @@ def destandardize(r, mean, std):
 def _gemm(fn, A, aoff, B, boff, Cm, coff, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0,
           bias=None, bias_off=0, sBias=0, accumulate=False):
     es = A.element_size()
-    call(fn, A.data_ptr() + aoff * es, B.data_ptr() + boff * es, Cm.data_ptr() + coff * 4, M, N, K, lda, ldb, ldc,
+    _timed_call("gemm", 2.0 * M * N * K * batch, fn, A.data_ptr() + aoff * es, B.data_ptr() + boff * es, Cm.data_ptr() + coff * 4, M, N, K, lda, ldb, ldc,
          int(tA), int(tB), batch, sA, sB, sC, (bias.data_ptr() + bias_off * 4) if bias is not None else None, sBias,
          int(accumulate), _stream())
 
@@ -196,6 +196,50 @@ def plt_decoder_wgrad(feat, g, out=None, accumulate=False):
         out = torch.empty(L, F, d, dtype=torch.float32, device=feat.device)
     _gemm(_fn_for(feat), feat, 0, g, 0, out, 0, F, d, Bn, L * F, L * d, d, True, False, batch=L, sA=F, sB=d, sC=F * d,
           accumulate=accumulate)
+    return out
+
+
+# ---- dense decoder / encoder-wgrad contractions with every operand k-contiguous (bf16 fast path) -------------
+# The glds MFMA kernel wants both operands k-contiguous ("NT").  Contractions whose natural layout is not
+# (decoder forward: K = features, weights stored [F][d]; weight gradients: K = tokens) get a transposed bf16
+# copy of one operand (cast_transpose_bf16) — the cast to bf16 is needed anyway.
+def transpose_cast_2d(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, ...] -> bf16 [prod(...), rows] (e.g. features [B, L, F] -> [L, F, B] flattened)."""
+    rows = x.shape[0]
+    return cast_transpose_bf16(x.reshape(1, rows, -1))[0]
+
+
+def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
+    """fo: bf16 [B, L, F]; WT: bf16 [L, d, F] (transposed weights)."""
+    Bn, L, F = fo.shape
+    d = WT.shape[1]
+    r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
+    _gemm("clt_gemm_bf16", _chk(fo, torch.bfloat16), 0, _chk(WT, torch.bfloat16), 0, r, 0, Bn, d, F, L * F, F, L * d, False, True,
+          batch=L, sA=F, sB=d * F, sC=d, bias=b, sBias=d)
+    return r
+
+
+def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Tensor:
+    """fo: bf16 [B, L, F]; WTs[l]: bf16 [(l+1), d, F].  Per target layer one batched GEMM over its source layers
+    (split-K by source layer) into fp32 slabs, summed in source-layer order (+ bias)."""
+    Bn, L, F = fo.shape
+    d = WTs[0].shape[1]
+    r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
+    slabs = torch.empty(L, Bn, d, dtype=torch.float32, device=fo.device)
+    for l in range(L):
+        _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], torch.bfloat16), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,
+              sA=F, sB=d * F, sC=Bn * d)
+        call("clt_sum_slabs_f32", slabs.data_ptr(), l + 1, Bn * d, Bn, d, L * d, (b.data_ptr() + 4 * l * d) if b is not None else None,
+             r.data_ptr() + 4 * l * d, _stream())
+    return r
+
+
+def wgrad_t(aT: torch.Tensor, bT: torch.Tensor, out: torch.Tensor, batch: int, sA: int, sB: int, accumulate=False):
+    """out[i] [M, N] (+)= aT[i] [M, K] @ bT[i] [N, K]^T with K = tokens; aT/bT are the token-minor (transposed) bf16
+    operands, e.g. features^T [L, F, B] and g^T [L, d, B]."""
+    M, N, K = out.shape[-2], out.shape[-1], aT.shape[-1]
+    _gemm("clt_gemm_bf16", _chk(aT, torch.bfloat16), 0, _chk(bT, torch.bfloat16), 0, out, 0, M, N, K, K, K, N, False, True,
+          batch=batch, sA=sA, sB=sB, sC=M * N, accumulate=accumulate)
     return out
 
 

@@ -63,6 +63,10 @@ int clt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
 int clt_gemm_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb,
                   long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                   const float* bias, long sBias, int accumulate, void* stream);
+/* out[r*ld_out + j] = bias[j] + sum_{s < nslab} slabs[s*slab_stride + r*n + j]: combines the per-source-layer
+ * partial products of the dense cross-layer decoder (split-K over source layers, clt.py:334-343). bias may be NULL. */
+int clt_sum_slabs_f32(const float* slabs, int nslab, long slab_stride, int rows, int n, long ld_out, const float* bias,
+                      float* out, void* stream);
 /* fp32 -> bf16 (RNE) copy, optionally transposing a [rows][cols] matrix (ld_in) to [cols][rows] (ld_out). */
 int clt_cast_bf16(const float* in, uint16_t* out, long n, void* stream);
 int clt_cast_transpose_bf16(const float* in, long ld_in, uint16_t* out, long ld_out, int rows, int cols,

@@ -140,3 +140,50 @@ def test_pretrained_roundtrip_and_folding(tmp_path, golden):
     with torch.no_grad():
         _, _, _, recons_folded = loaded(batch[:, 0])
     assert_close(recons_folded, recons, 1e-4, 1e-4 * float(recons.abs().max()), "folded recons")
+
+
+@pytest.mark.parametrize("dec_kind,nl_kind,loss_kind", [("clt", "jumprelu", "jumprelu"), ("plt", "jumprelu", "jumprelu"),
+                                                        ("clt", "relu", "base"), ("clt", "batchtopk", "base")])
+def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
+    """Shapes large enough for the glds NT GEMM kernel (K % 64 == 0, M*N >= 256^2) in every dense contraction
+    (decoder forward with transposed weights + slab sum, dgrad, token-contracted weight gradients): loss and
+    gradients vs the oracle run with the same bf16 operand rounding (rtol 2e-2, relative l2 for gradients)."""
+    from crosslayer_transcoder_amd import precision
+    from oracle import clt_oracle as O
+    from tests.build_cases import build_module
+    B, L, d, F = 512, 3, 128, 512
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, L, d, generator=g)
+    y = 0.5 * x * torch.randn(L, d, generator=g) + 0.1 * torch.randn(B, L, d, generator=g)
+    batch = torch.stack([x, y], 1)
+    nl = {"relu": {"kind": "relu"}, "jumprelu": {"kind": "jumprelu", "theta": 0.05, "bandwidth": 0.1},
+          "batchtopk": {"kind": "batchtopk", "k": 8, "e": 0.1}}[nl_kind]
+    lc = {"kind": "base"} if loss_kind == "base" else {"kind": "jumprelu", "lambda_sparsity": 0.05, "c_sparsity": 1.0,
+                                                       "use_tanh": True, "pre_actv_loss": 1e-3}
+    cfg = {"decoder": dec_kind, "d_features": F, "nonlinearity": nl, "loss": lc}
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.randn(L, F, generator=g) * 0.01,
+              "decoder.b": torch.randn(L, d, generator=g) * 0.01}
+    bd = (d * L) ** -0.5
+    if dec_kind == "clt":
+        for l in range(L):
+            params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * bd
+    else:
+        params["decoder.W"] = (torch.rand(L, F, d, generator=g) * 2 - 1) * bd
+    if nl_kind == "jumprelu":
+        params["nonlinearity.theta"] = torch.full((1, L, F), 0.05)
+    case = {"cfg": cfg, "opt": {"lr": 1e-3}, "batches": batch[None], "init_params": params,
+            "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+    mod = build_module(case)
+    mod.global_step = 5
+    with precision("bf16-mixed"):
+        out = mod.compute_step(batch.cuda(), 0, sparse=False)
+    c = dict(cfg); c["loss"] = dict(lc, step_frac=0.5)
+    buf = {"last_active": torch.zeros(L, F, dtype=torch.long), "threshold": torch.zeros(1)}
+    with O.operand_rounding(torch.bfloat16):
+        ref = O.training_step(batch, params, O.standardizer_init(batch), c, buf)
+    assert_close(out["loss"], ref["loss"], 2e-3, 1e-6, "loss")
+    assert_close(out["recons_norm"], ref["recons_norm"], 2e-2, 2e-2 * float(ref["recons_norm"].abs().max()), "recons_norm")
+    for k, gref in ref["grads"].items():
+        gg = out["grads"][k].reshape(gref.shape).cpu()
+        rel = (gg - gref).norm() / (gref.norm() + 1e-12)
+        assert rel < 2e-2, f"{dec_kind}/{nl_kind} bf16 grad {k}: rel l2 err {rel:.3g}"
