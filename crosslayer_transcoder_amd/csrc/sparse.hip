@@ -86,12 +86,18 @@ struct RowPassArgs {
     float lr, omb1, b2, omb2, eps, wd, step_size, isb2; int adamw;
 };
 
-template <int NT, bool VEC>
-__global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
+// CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
+// 16-byte lanes).  CW > 1 (long rows, e.g. d = 4096): one row per block, wave c owns the c-th 1024-float chunk —
+// keeps the per-lane state at NT = 4 (high occupancy) and combines the per-entry dots through LDS in wave order.
+template <int NT, bool VEC, int CW>
+__global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
     constexpr int W = VEC ? 4 : 1;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float shdot[2][CW];
+    const int wave = threadIdx.x >> 6;
+    const int r = CW == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (r >= a.rows) return;
     const int lane = threadIdx.x & 63;
+    const int cb = CW == 1 ? 0 : wave * NT * 64 * W;          // first element of this wave's chunk
     const int col = a.col0 + r;
     const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
     const long srs = (long)a.L * a.d;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
     const bool need_w = a.dot_out != nullptr || a.dot_out2 != nullptr || a.grad_out == nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int o = (t * 64 + lane) * W;
+        const int o = cb + (t * 64 + lane) * W;
 #pragma unroll
         for (int c = 0; c < W; ++c) { g[t][c] = 0.0f; wv[t][c] = 0.0f; }
         if (need_w && o < a.d) {
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
             float dot = 0.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int o = (t * 64 + lane) * W;
+                const int o = cb + (t * 64 + lane) * W;
                 if (o < a.d) {
                     if (VEC) {
                         const float4 s = *reinterpret_cast<const float4*>(srow + o);
@@ -137,15 +143,24 @@ __global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
             csum += cv;
             if (dout) {
                 dot = wave_sum(dot);
-                if (lane == 0) dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p] = dot;
+                if (CW > 1) {                                   // every wave of the block walks the same entry list
+                    const int par = (int)((p - p0) & 1u);
+                    if (lane == 0) shdot[par][wave] = dot;
+                    __syncthreads();
+                    dot = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) dot += shdot[par][c];
+                }
+                if (lane == 0 && wave == (CW == 1 ? wave : 0))
+                    dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p] = dot;
             }
         }
     }
-    if (a.colsum_out && lane == 0) a.colsum_out[col] = csum;
+    if (a.colsum_out && lane == 0 && (CW == 1 || wave == 0)) a.colsum_out[col] = csum;
     if (a.grad_out) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int o = (t * 64 + lane) * W;
+            const int o = cb + (t * 64 + lane) * W;
             if (o < a.d) {
                 if (VEC) *reinterpret_cast<float4*>(a.grad_out + ro + o) = make_float4(g[t][0], g[t][1 % W], g[t][2 % W], g[t][3 % W]);
                 else a.grad_out[ro + o] = g[t][0];
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(TPB) void row_pass_kernel(RowPassArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int o = (t * 64 + lane) * W;
+        const int o = cb + (t * 64 + lane) * W;
         if (o >= a.d) continue;
         float mm[W], vv[W];
         if (VEC) {
@@ -307,7 +322,28 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     const bool vec = d % 4 == 0 && aligned16(W) && aligned16(src) && (!m || aligned16(m)) && (!v || aligned16(v)) &&
                      (!grad_out || aligned16(grad_out)) && (!src2 || aligned16(src2)) &&
                      (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
-    DISPATCH_NT(row_pass_kernel, dim3((rows + 3) / 4), as_stream(stp), d, vec, a);
+    hipStream_t st = as_stream(stp);
+    const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);   // 64-lane iterations a whole row needs
+    const dim3 g4((rows + 3) / 4), g1(rows);
+#define RP(NT_, VEC_, CW_, GRID_) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a)
+    if (vec) {
+        if (chunks <= 1) RP(1, true, 1, g4);
+        else if (chunks <= 2) RP(2, true, 1, g4);
+        else if (chunks <= 3) RP(3, true, 1, g4);
+        else if (chunks <= 4) RP(4, true, 1, g4);
+        else if (chunks <= 8) RP(4, true, 2, g1);
+        else if (chunks <= 16) RP(4, true, 4, g1);
+        else if (chunks <= 32) RP(4, true, 8, g1);
+        else if (chunks <= 64) RP(4, true, 16, g1);
+        else return CLT_ERR_RANGE;
+    } else {
+        if (chunks <= 1) RP(1, false, 1, g4);
+        else if (chunks <= 2) RP(2, false, 1, g4);
+        else if (chunks <= 4) RP(4, false, 1, g4);
+        else if (chunks <= 16) RP(16, false, 1, g4);
+        else return CLT_ERR_RANGE;
+    }
+#undef RP
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 

@@ -286,7 +286,8 @@ def _sparse_features(B, L, F, k, seed):
     return feat
 
 
-@pytest.mark.parametrize("B,L,F,d,k", [(16, 2, 32, 110, 4), (33, 3, 100, 20, 7), (8, 12, 512, 768, 16), (5, 2, 40, 7, 40)])
+@pytest.mark.parametrize("B,L,F,d,k", [(16, 2, 32, 110, 4), (33, 3, 100, 20, 7), (8, 12, 512, 768, 16), (5, 2, 40, 7, 40),
+                                       (7, 3, 40, 1536, 4), (6, 2, 48, 4096, 5)])
 def test_sparse_lists_and_decoder(ops, B, L, F, d, k):
     """CSR/CSC construction is exact; gather forward and the fused row pass (dW, dots, Adam) match the dense
     oracle formulas."""
