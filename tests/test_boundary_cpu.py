@@ -1,0 +1,110 @@
+"""Host-side boundary checks that need no GPU: the C-ABI library exports every symbol include/clt_hip.h declares
+(and the ctypes table binds exactly those), and the drop-in classes keep the reference's constructor arguments,
+parameter names / logical shapes, config schema and error behaviour (reference tests/test_save_to_pretrained.py:64-91,
+tests/test_load_from_pretrained.py:52-54, model/topk.py:56, model/standardize.py:54-55)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CONFIGS = "/root/reference/config"
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "clt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(clt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from crosslayer_transcoder_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/clt_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert _lib.lib.clt_arch() == b"gfx950" and _lib.lib.clt_abi_version() == _lib.ABI_VERSION
+    # size queries are pure host code
+    assert _lib.lib.clt_select_lists_workspace_bytes(4096, 12, 32768, 16, 1) > 0
+    assert _lib.lib.clt_sparse_build_workspace_bytes(16, 2, 32) == (32 + 3 * 64 + 64) * 4
+
+
+def _model(nl, dec="clt", L=2, d=110, F=32):
+    from crosslayer_transcoder_amd.model import CrossLayerTranscoder, CrosslayerDecoder, Decoder, Encoder
+    from crosslayer_transcoder_amd.model.standardize import DimensionwiseInputStandardizer, DimensionwiseOutputStandardizer
+    D = CrosslayerDecoder if dec == "clt" else Decoder
+    return CrossLayerTranscoder(nl, Encoder(d, F, L), D(d, F, L), DimensionwiseInputStandardizer(L, d),
+                                DimensionwiseOutputStandardizer(L, d))
+
+
+def test_parameter_names_shapes_and_config_schema():
+    from crosslayer_transcoder_amd.model import BatchTopK, JumpReLU, PerLayerBatchTopK, PerLayerTopK, ReLU
+    L, d, F = 2, 110, 32
+    for dec in ("clt", "plt"):
+        for nl in (ReLU(), JumpReLU(theta=0.03, bandwidth=0.01, n_layers=L, d_features=F), PerLayerTopK(k=4),
+                   BatchTopK(k=4, e=0.1), PerLayerBatchTopK(k=4, e=0.1, n_layers=L)):
+            m = _model(nl, dec, L, d, F)
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            assert shapes["encoder.W"] == (L, d, F) and shapes["encoder.b"] == (L, F) and shapes["decoder.b"] == (L, d)
+            if dec == "clt":
+                assert all(shapes[f"decoder.W_{l}"] == (l + 1, F, d) for l in range(L))
+            else:
+                assert shapes["decoder.W"] == (L, F, d)
+            assert shapes["input_standardizer.mean"] == (L, d) and shapes["output_standardizer.std"] == (L, d)
+            if isinstance(nl, JumpReLU):
+                assert shapes["nonlinearity.theta"] == (1, L, F)
+            if isinstance(nl, (BatchTopK, PerLayerBatchTopK)):
+                assert shapes["nonlinearity.threshold"] == ((L,) if isinstance(nl, PerLayerBatchTopK) else (1,))
+            cfg = m.to_config()
+            assert cfg["class_path"] == "crosslayer_transcoder.model.clt.CrossLayerTranscoder"
+            assert cfg["init_args"]["encoder"] == {"class_path": "crosslayer_transcoder.model.clt.Encoder",
+                                                   "init_args": {"d_acts": d, "d_features": F, "n_layers": L}}
+            again = type(m).from_config(yaml.safe_load(yaml.dump(cfg)))
+            assert {k: tuple(v.shape) for k, v in again.state_dict().items()} == shapes
+    # the encoder weight is stored feature-major but keeps the reference's logical layout
+    enc = _model(ReLU()).encoder
+    assert enc.W.permute(0, 2, 1).is_contiguous()
+
+
+def test_error_conventions_without_gpu():
+    from crosslayer_transcoder_amd.model import PerLayerTopK
+    from crosslayer_transcoder_amd.model.clt_lightning import CrossLayerTranscoderModule
+    from crosslayer_transcoder_amd.model.standardize import DimensionwiseInputStandardizer
+    with pytest.raises(AssertionError):                      # k > d_features (model/topk.py:56)
+        PerLayerTopK(k=6)(torch.zeros(3, 4, 5))
+    with pytest.raises(ValueError):                          # "Standardizer not initialized" (standardize.py:54-55)
+        DimensionwiseInputStandardizer(2, 4)(torch.zeros(1, 2, 4))
+    from crosslayer_transcoder_amd.model import ReLU
+    mod = CrossLayerTranscoderModule(model=_model(ReLU()), optimizer="sgd")
+    with pytest.raises(ValueError):                          # unknown optimizer (clt_lightning.py:353-354)
+        mod.configure_optimizers()
+    with pytest.raises(RuntimeError):                        # no CPU fallback in the product path
+        mod.compute_step(torch.zeros(4, 2, 2, 110), 0)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference configs not present on this machine")
+@pytest.mark.parametrize("name", ["debug-cpu.yaml", "default.yaml", "jumprelu-clt.yaml", "topk-clt.yaml"])
+def test_reference_yaml_configs_instantiate(name):
+    """The reference's own LightningCLI YAML files build the drop-in module tree unchanged (class_path prefixes are
+    mapped; eval-time metric objects are dropped).  Large configs are only checked structurally (meta device)."""
+    from crosslayer_transcoder_amd import trainer
+    path = os.path.join(REF_CONFIGS, name)
+    if not os.path.exists(path):
+        pytest.skip("config not in this reference version")
+    cfg = trainer.load_config(path)
+    small = name == "debug-cpu.yaml"
+    with torch.device("cpu" if small else "meta"):
+        mod = trainer.build_module(cfg)
+    want = cfg["model"]["class_path"].rsplit(".", 1)[1]
+    assert type(mod).__name__ == want
+    enc_args = cfg["model"]["init_args"]["model"]["init_args"]["encoder"]["init_args"]
+    assert tuple(mod.model.encoder.W.shape) == (enc_args["n_layers"], enc_args["d_acts"], enc_args["d_features"])
+    conf = mod.configure_optimizers() if small else None
+    if small:
+        opt = conf["optimizer"] if isinstance(conf, dict) else conf
+        assert opt.param_groups[0]["lr"] == cfg["model"]["init_args"]["learning_rate"]
