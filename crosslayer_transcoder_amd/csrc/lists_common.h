@@ -170,4 +170,20 @@ __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __
     }
 }
 
+
+// rows mode: pack the [rows][k] compact rows (ascending feature id, valid count in row_cnt) into the CSR
+__global__ __launch_bounds__(LTPB) void compact_rows_kernel(const int32_t* __restrict__ cidx, const float* __restrict__ cval, int k, int F, int L,
+                                                           int rows, const uint32_t* __restrict__ row_start, uint32_t cap,
+                                                           int32_t* __restrict__ ent_col, float* __restrict__ ent_val,
+                                                           int32_t* __restrict__ overflow) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t s = row_start[row], n = row_start[row + 1] - s;
+    const int colbase = (row % L) * F;
+    for (uint32_t e = threadIdx.x & 63; e < n; e += 64) {
+        if (s + e < cap) { ent_col[s + e] = colbase + cidx[(long)row * k + e]; ent_val[s + e] = cval[(long)row * k + e]; }
+        else *overflow = 1;
+    }
+}
+
 }  // namespace

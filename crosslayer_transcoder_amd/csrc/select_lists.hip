@@ -289,21 +289,6 @@ __global__ void scatter_rows_kernel(const uint32_t* __restrict__ sel_idx, const 
     }
 }
 
-// rows mode: pack the [rows][k] compact rows (ascending feature id, valid count in row_cnt) into the CSR
-__global__ __launch_bounds__(TPB) void compact_rows_kernel(const int32_t* __restrict__ cidx, const float* __restrict__ cval, int k, int F, int L,
-                                                           int rows, const uint32_t* __restrict__ row_start, uint32_t cap,
-                                                           int32_t* __restrict__ ent_col, float* __restrict__ ent_val,
-                                                           int32_t* __restrict__ overflow) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const uint32_t s = row_start[row], n = row_start[row + 1] - s;
-    const int colbase = (row % L) * F;
-    for (uint32_t e = threadIdx.x & 63; e < n; e += 64) {
-        if (s + e < cap) { ent_col[s + e] = colbase + cidx[(long)row * k + e]; ent_val[s + e] = cval[(long)row * k + e]; }
-        else *overflow = 1;
-    }
-}
-
 __global__ void masked_copy_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, long total, long n,
                                    float* __restrict__ out, const int32_t* __restrict__ gate) {
     if (gate && *gate == 0) return;

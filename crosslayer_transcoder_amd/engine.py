@@ -48,8 +48,7 @@ def _select_lists(nl, pre, col_mask=None, shard=None):
     assert nl.k <= (F if shard is None else shard.F_global)
     if shard is not None:
         if isinstance(nl, PerLayerTopK):
-            raise NotImplementedError("PerLayerTopK under feature sharding is not implemented (BatchTopK / "
-                                      "PerLayerBatchTopK, ReLU and JumpReLU are)")
+            return ops.select_rows_sharded(pre, nl.k, shard, col_mask)
         if nl.k > 0 and nl.e is None:
             raise TypeError("BatchTopK needs `e` (threshold EMA rate) for training")
         mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH

@@ -590,6 +590,40 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
     return s
 
 
+def select_rows_sharded(x: torch.Tensor, k: int, shard, col_mask: Optional[torch.Tensor] = None,
+                        cap: Optional[int] = None) -> SparseLists:
+    """Feature-sharded PerLayerTopK: k of shard.F_global per (b, l) row; x = this rank's [B, L, F_local]."""
+    from .parallel import run_sharded_rows_selection
+    _chk(x)
+    Bn, L, F = x.shape
+    assert F == shard.F_local
+    if k > shard.F_global:
+        raise AssertionError("k must be <= d_features")
+    if min(k, F) > 2048:
+        raise NotImplementedError("sharded per-row TopK supports k <= 2048")
+    if cap is None:
+        cap = max(1, min(k, F) * Bn * L)
+    s = _empty_lists(Bn, L, F, cap, x.device)
+    dims = (Bn, L, F, k, shard.world)
+    ws = workspace(lib.clt_select_rows_sharded_workspace_bytes(*dims), x.device)
+    off = [lib.clt_select_rows_sharded_exchange_info(*dims, w) for w in range(4)]
+    i32 = lambda o, n: ws[o:o + 4 * n].view(torch.int32)  # noqa: E731
+    exchange = {"counts": i32(off[0], off[1]), "ties": i32(off[2], off[3] * shard.world).view(shard.world, off[3])}
+    if col_mask is not None:
+        _chk(col_mask, torch.uint8)
+
+    def stages(lo, hi):
+        call("clt_select_rows_sharded_f32", lo, hi, shard.world, shard.rank, shard.F_global, x.data_ptr(),
+             col_mask.data_ptr() if col_mask is not None else None, Bn, L, F, k, s.cap, s.row_start.data_ptr(),
+             s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(),
+             s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), ws.data_ptr(), ws.numel(),
+             _stream())
+
+    run_sharded_rows_selection(stages, shard, exchange)
+    s.used_fallback = torch.zeros(1, dtype=torch.int32, device=x.device)
+    return s
+
+
 def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
     """Device array of device pointers (one small H2D copy; cache it while the storages are stable)."""
     return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(tensors[0].device)

@@ -83,6 +83,17 @@ def run_sharded_selection(stages, shard: FeatureShard, S: int, exchange):
     stages(5, 5)
 
 
+def run_sharded_rows_selection(stages, shard: FeatureShard, exchange):
+    """Collective schedule of the sharded per-row TopK (clt_select_rows_sharded_f32): eight 4-bit radix rounds, each
+    closed by an all-reduce(sum) of the [rows*16] bucket counts, then an all-gather of the per-row tie counts."""
+    for st in range(8):
+        stages(st, st)
+        shard.all_reduce_sum(exchange["counts"])
+    stages(8, 8)
+    shard.all_gather_blocks(exchange["ties"])
+    stages(9, 9)
+
+
 def shard_module(mod, shard: FeatureShard):
     """Turn a full-size training module (identical on every rank, e.g. same seed or same checkpoint) into this
     rank's shard IN PLACE: parameters and buffers with a feature axis keep only [f_off, f_off + F_local).

@@ -215,6 +215,18 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
                                  float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                                  uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* Feature-sharded per-row TopK (mode 0 under sharding; k <= 2048): local top-k rows, then the exact global k-th value
+ * of every row by 8 rounds of 4-bit radix counts.  Stages stage_lo..stage_hi with host collectives in between:
+ *   after stages 0..7: SUM over ranks of the uint32 array at exchange offset 0 (length info 1 = rows*16)
+ *   after stage 8:     ALL-GATHER of the [world][rows] uint32 tie counts at exchange offset 2 (rank r fills block r)
+ *   stage 9: keep/drop (ties in global feature order = rank order, then index order) + rank-local list build. */
+size_t clt_select_rows_sharded_workspace_bytes(int B, int L, int F, int k, int world);
+size_t clt_select_rows_sharded_exchange_info(int B, int L, int F, int k, int world, int which);
+int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank, int F_global, const float* x,
+                                const uint8_t* col_mask, int B, int L, int F, int k, uint32_t cap, uint32_t* row_start,
+                                int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
+                                int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
+                                size_t ws_bytes, void* stream);
 /* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
  * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
  * Wptr: DEVICE array of L device pointers. */

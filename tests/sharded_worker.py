@@ -56,6 +56,8 @@ def gpu_case(name, fuse_adam):
                 assert_close(g.reshape(gref.shape), gref, 1e-4, 2e-6 * float(rec["grads"][k].abs().max()) + 1e-12, f"grad {k}")
         assert torch.equal(mod.last_active.cpu(), sl(rec["last_active"], 1)), f"last_active {t}"
         assert_close(out["terms"]["dead_fraction"], rec["logged"]["metrics/dead_features"], 1e-6, 1e-7, "dead")
+        if "training/aux_loss" in rec["logged"]:
+            assert_close(out["terms"]["aux"], rec["logged"]["training/aux_loss"], 5e-5, 1e-7, "aux")
         if "training/sparsity_loss" in rec["logged"]:
             assert_close(out["terms"]["sparsity"], rec["logged"]["training/sparsity_loss"], 5e-5, 1e-8, "sparsity")
             assert_close(out["terms"]["pre_actv"], rec["logged"]["training/pre_actv_loss"], 5e-5, 1e-10, "pre_actv")
@@ -69,6 +71,38 @@ def gpu_case(name, fuse_adam):
     ref = b.clone()
     shard.all_reduce_min(ref)
     assert torch.equal(b, ref), "decoder.b diverged between ranks"
+
+
+def gpu_selection_ties(rank, world):
+    """Sharded selections on tie-heavy inputs vs the oracle's rule (larger value, then lower GLOBAL index)."""
+    from crosslayer_transcoder_amd import ops
+    from crosslayer_transcoder_amd.parallel import FeatureShard
+    from oracle import clt_oracle as O
+    g = torch.Generator().manual_seed(3)
+    for B, L, F, ks in ((40, 3, 512, (1, 7, 100)), (9, 2, 64, (3, 40)), (33, 4, 256, (16,))):
+        shard = FeatureShard(F)
+        for tie_heavy in (True, False):
+            # 24 distinct values: thousands of exact ties at every threshold, yet < 4096 per shard and segment (the
+            # documented limit of the sharded batch modes; the per-row mode has no such limit)
+            x = (torch.randint(0, 24, (B, L, F), generator=g).float() - 3.0) if tie_heavy else torch.randn(B, L, F, generator=g)
+            xl = shard.slice_features(x, 2).contiguous().cuda()
+            mask = (torch.rand(L, F, generator=g) < 0.4)
+            for k in ks:
+                for cm in (None, mask):
+                    xm = x if cm is None else torch.where(cm.expand_as(x), x, torch.full_like(x, -float("inf")))
+                    cml = None if cm is None else shard.slice_features(cm, 1).to(torch.uint8).contiguous().cuda()
+                    S = ops.select_rows_sharded(xl, k, shard, cml)
+                    want = shard.slice_features(O.per_layer_topk_fwd(xm, k)[0], 2)
+                    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), want), f"rows k={k} ties={tie_heavy}"
+                    thr = torch.zeros(1, device="cuda")
+                    S = ops.select_lists_sharded(xl, k, ops.SELECT_BATCH, shard, thr, 0.1, cml)
+                    ref, _, mk = O.batch_topk_fwd(xm, k)
+                    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), \
+                        f"batch k={k} ties={tie_heavy} mask={cm is not None}"
+                    S = ops.select_lists_sharded(xl, k, ops.SELECT_LAYER, shard, torch.zeros(L, device="cuda"), 0.1, cml)
+                    ref = O.per_layer_batch_topk_fwd(xm, k)[0]
+                    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), \
+                        f"layer k={k} ties={tie_heavy}"
 
 
 def sim_selection(rank, world):
@@ -169,7 +203,8 @@ def sim_selection(rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sim", action="store_true")
-    ap.add_argument("--cases", default="batchtopk_clt_base,relu_clt_base,dbg_jumprelu_clt,jumprelu_plt_notanh")
+    ap.add_argument("--cases", default="batchtopk_clt_base,relu_clt_base,dbg_jumprelu_clt,jumprelu_plt_notanh,topk_clt_aux,"
+                    "batchtopk_clt_aux,perlayerbatchtopk_clt_aux,topk_plt_aux_fewdead")
     args = ap.parse_args()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -178,6 +213,7 @@ def main():
             sim_selection(rank, world)
         else:
             torch.cuda.set_device(0)
+            gpu_selection_ties(rank, world)
             for name in args.cases.split(","):
                 for fuse in (False, True):
                     gpu_case(name, fuse)
