@@ -29,10 +29,21 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
 #define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
+// Epilogue 1 ("select"): instead of storing C, every element >= the segment's lower-bound key is appended as
+// (order-preserving key, flat index batch*sC + row*ldc + col) to the candidate list of the TopK selection
+// (select_lists.hip) — the 6.4 GB pre-activation tensor is then neither written nor re-read.
+struct SelEpi {
+    const uint32_t* ctl;          // SelCtl records of 4 words: [lb key, candidate count, -, -]
+    uint32_t* cand_key; uint32_t* cand_idx; uint32_t capS;
+    int seg_per_batch;            // 1: segment = batch index (per-layer selection); 0: one segment
+};
+constexpr int ESTG = 2048;       // block-level candidate staging entries in LDS
+
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                            float* __restrict__ C, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias,
-                                                           long sBias, int accumulate, int tilesA, int tilesB, int diag) {
+                                                           long sBias, int accumulate, int tilesA, int tilesB, int diag, SelEpi se) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     // ---- block -> (batch, tile) with an XCD-aware, bijective remap ------------------------------------
@@ -45,7 +56,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
     const int ta = lid % tilesA, tb = lid / tilesA;
     const int a0 = ta * TA, b0 = tb * TB;
-    A += (long)batch * sA; B += (long)batch * sB; C += (long)batch * sC;
+    A += (long)batch * sA; B += (long)batch * sB;
+    if (EPI == 0) C += (long)batch * sC;
     if (bias) bias += (long)batch * sBias;
 
     // ---- staging addresses: per glds instruction a wave fills 8 rows x 128 B ---------------------------
@@ -111,6 +123,77 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         __syncthreads();
     }
 
+    if (EPI == 1) {
+        // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
+        uint32_t* skey = reinterpret_cast<uint32_t*>(nt_smem);
+        uint32_t* sidx = skey + ESTG;
+        uint32_t* scnt = sidx + ESTG;                     // [0] staged count, [1] global base
+        const int seg = se.seg_per_batch ? batch : 0;
+        uint32_t* gcnt = const_cast<uint32_t*>(se.ctl) + 4 * seg + 1;
+        const uint32_t lb = se.ctl[4 * seg];
+        uint32_t* ck = se.cand_key + (size_t)seg * se.capS;
+        uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
+        if (tid == 0) scnt[0] = 0;
+        __syncthreads();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const float lbf = key_f32(lb);                    // fast reject in float: !(v < lbf) also lets NaNs through
+        f32x4 bv[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int col = b0 + wm * 128 + m * 16 + fq * 4;
+            bv[m] = (bias && col < N) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int row = a0 + wn * 64 + n * 16 + fr;
+            const uint32_t flat_row = (uint32_t)((long)batch * sC + (long)row * ldc);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int col = b0 + wm * 128 + m * 16 + fq * 4;
+                const f32x4 v = acc[m][n] + bv[m];
+                const bool in = row < M && col < N;
+                const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
+                if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
+                uint32_t key[4]; bool pr[4]; unsigned long long bm[4]; uint32_t tot = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    key[c] = f32_key(v[c]);
+                    pr[c] = in && key[c] >= lb;
+                    bm[c] = __ballot(pr[c]);
+                    tot += (uint32_t)__popcll(bm[c]);
+                }
+                if (tot == 0) continue;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&scnt[0], tot);
+                base = __shfl(base, 0, 64);
+                uint32_t off = base;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) off += (uint32_t)__popcll(bm[c] & lt);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (pr[c]) {
+                        const uint32_t fi = flat_row + (uint32_t)(col + c);
+                        if (off < (uint32_t)ESTG) { skey[off] = key[c]; sidx[off] = fi; }
+                        else {                               // staging full (pathological tile): straight to the global list
+                            const uint32_t pos = atomicAdd(gcnt, 1u);
+                            if (pos < se.capS) { ck[pos] = key[c]; ci[pos] = fi; }
+                        }
+                        ++off;
+                    }
+            }
+        }
+        __syncthreads();
+        const uint32_t staged = min(scnt[0], (uint32_t)ESTG);
+        if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
+        __syncthreads();
+        const uint32_t gbase = scnt[1];
+        for (uint32_t i = tid; i < staged; i += 512) {
+            const uint32_t pos = gbase + i;
+            if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
+        }
+        return;
+    }
+
     // ---- epilogue ---------------------------------------------------------------------------------------
     // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
     // transposes its 64 x 128 sub-tile through a private LDS region (two halves of 32 rows, 528-byte padded rows:
@@ -159,10 +242,33 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
     const long nblk = (long)tilesA * tilesB * batch;
     if (nblk > 0x7fffffffL) return 1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((unsigned)nblk), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, ldc, sA, sB,
-                       sC, bias, sBias, accumulate, tilesA, tilesB, getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0);
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)nblk), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, ldc, sA,
+                       sB, sC, bias, sBias, accumulate, tilesA, tilesB, getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0,
+                       SelEpi{});
+    CLT_LAUNCH_CHECK();
+    return CLT_OK;
+}
+
+// C is never written: candidates (key >= ctl[seg].lb) go to the selection workspace.  ldc / sC only define the flat
+// index of an element.  Returns 1 when the shape does not qualify for the fast kernel.
+extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, long ldc, int batch,
+                                    long sA, long sB, long sC, const float* bias, long sBias, const uint32_t* ctl,
+                                    uint32_t* cand_key, uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !ctl || !cand_key || !cand_idx || capS == 0) return CLT_ERR_SHAPE;
+    const bool ok = K % TK == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
+                    aligned16(A) && aligned16(B) && (!bias || aligned16(bias));
+    if (!ok) return 1;
+    if ((unsigned long long)(batch - 1) * sC + (unsigned long long)(M - 1) * ldc + N > 0xffffffffull) return CLT_ERR_RANGE;
+    const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
+    const long nblk = (long)tilesA * tilesB * batch;
+    if (nblk > 0x7fffffffL) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)nblk), dim3(512), LDS_BYTES, as_stream(stream), A, B, (float*)nullptr, M,
+                       N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, 0, SelEpi{ctl, cand_key, cand_idx, capS,
+                       seg_per_batch});
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -79,6 +79,17 @@ __global__ __launch_bounds__(TPB) void sample_kernel(uint32_t ns, uint32_t rank,
     if (threadIdx.x == 0) ctl[s].lb = prefix;
 }
 
+// ext mode, stage 0: lower bound from the previous step's exact k-th value (positive, else the attempt is void)
+__global__ void ext_lb_kernel(const uint32_t* __restrict__ prev_T, float margin, int S, uint32_t Kseg, SegState* __restrict__ state,
+                              SelCtl* __restrict__ ctl, Head* __restrict__ head) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const float T = key_f32(prev_T[s]);
+        if (!(T > 0.0f) || !(T < INFINITY)) head->gate = 1;
+        ctl[s].lb = f32_key(T * margin);
+        SegState st; st.prefix = 0; st.mask = 0; st.krem = Kseg; st.eq_total = 0; state[s] = st;
+    }
+}
+
 // ---- stage 1: one streaming pass, candidates >= lb -------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(TPB) void filter_kernel(const float* __restrict__ x, const uint8_t* __restrict__ col_mask, int F, int L,
@@ -306,8 +317,9 @@ struct LPlan {
 };
 
 // Kseg = k * (rows of a segment): the GLOBAL number of selected entries of a segment; a shard expects 1/world of it.
-LPlan lplan(int B, int L, int F, int k, int mode, int world, int exhaustive) {
+LPlan lplan(int B, int L, int F, int k, int mode, int world, int flags) {
     LPlan p;
+    const int exhaustive = flags & 1, ext = flags & 2;   // ext: candidates come from the GEMM epilogue (lb from the last step)
     p.S = mode == 2 ? L : 1;
     p.RS = mode == 2 ? B : B * L;
     p.rows = B * L; p.ncols = L * F;
@@ -319,7 +331,7 @@ LPlan lplan(int B, int L, int F, int k, int mode, int world, int exhaustive) {
     const double m = (double)p.ns * (double)Kloc / (double)nseg;
     const double r = m + 8.0 * sqrt(m) + 32.0;
     p.rank = (exhaustive || r >= (double)p.ns) ? p.ns : (uint32_t)r;
-    unsigned long long capS = 4ull * Kloc + 65536ull;
+    unsigned long long capS = (ext ? 6ull : 4ull) * Kloc + 65536ull;
     if (capS > nseg || exhaustive) capS = nseg;
     p.capS = (uint32_t)capS;
     p.rpb = 16; if (p.rpb > p.RS) p.rpb = p.RS;
@@ -360,6 +372,7 @@ struct SelArgs {
     uint32_t* row_start; int32_t* ent_col; float* ent_val; uint32_t* col_start; int32_t* csc_tok; float* csc_val;
     int32_t* csc_ent; uint8_t* fired; uint32_t* total; int32_t* overflow; float* dense_scratch; int32_t* used_fallback;
     void* ws; size_t wsb; hipStream_t st; Shard sd; int exhaustive;
+    const uint32_t* prev_T; float margin;        // ext mode (exhaustive & 2): lower bound = margin * last step's k-th value
 };
 
 // Stages (batch modes):  0 clear + sample -> lb            [sharded: MIN of lb over ranks]
@@ -376,7 +389,6 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     const unsigned long long nall = (unsigned long long)B * L * (a.sd.world > 1 ? a.sd.F_global : (uint32_t)F);
     if (nall >= 0xffffffffull || (unsigned long long)L * F >= 0x7fffffffull) return CLT_ERR_RANGE;
     if (mode == 0 && (k > 2048 || a.sd.world > 1)) return CLT_ERR_RANGE;
-    if (mode != 0 && a.sd.world == 1 && !a.dense_scratch) return CLT_ERR_SHAPE;
     hipStream_t st = a.st;
     const int rows = B * L, ncols = L * F;
     if (k == 0) {                                          // topk.py:86-87: nothing selected, no threshold update
@@ -419,6 +431,10 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             if (a.used_fallback && hipMemsetAsync(a.used_fallback, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
             if (hipMemsetAsync(a.ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
             if (mode == 0) continue;
+            if (a.exhaustive & 2) {
+                hipLaunchKernelGGL(ext_lb_kernel, dim3(1), dim3(64), 0, st, a.prev_T, a.margin, p.S, p.Kseg, state, ctl, head);
+                continue;
+            }
             if (p.rank < p.ns)
                 hipLaunchKernelGGL(sample_gather_kernel, dim3((p.ns + TPB - 1) / TPB, p.S), dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S,
                                    p.RS, p.ns, sample);
@@ -433,7 +449,8 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                a.ent_col, a.ent_val, a.overflow);
         } else if (stage == 1) {
             const dim3 fgrid(p.NC, p.S);
-            if (F % 4 == 0 && aligned16(a.x))
+            if (a.exhaustive & 2) { /* candidates were appended by clt_gemm_bf16_select */ }
+            else if (F % 4 == 0 && aligned16(a.x))
                 hipLaunchKernelGGL((filter_kernel<true>), fgrid, dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
             else
                 hipLaunchKernelGGL((filter_kernel<false>), fgrid, dim3(TPB), 0, st, a.x, a.col_mask, F, L, p.S, p.RS, p.rpb, ctl, p.capS, ckey, cidx);
@@ -471,7 +488,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
         hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, a.col_start, a.csc_tok, a.csc_val, a.csc_ent, long_list,
                            &head->long_cols, gate, 0);
         CLT_LAUNCH_CHECK();
-        if (mode != 0 && a.sd.world == 1) {                // exhaustive path, enqueued always, runs only when gated in
+        if (mode != 0 && a.sd.world == 1 && a.dense_scratch) {   // exhaustive path, enqueued always, runs only when gated in
             const float* src = a.x;
             if (a.col_mask) {
                 hipLaunchKernelGGL(masked_copy_kernel, dim3(4096), dim3(TPB), 0, st, a.x, a.col_mask, (long)nall, (long)ncols,
@@ -507,7 +524,9 @@ int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, 
                          uint32_t* total, int32_t* overflow, float* dense_scratch, int32_t* used_fallback, void* ws,
                          size_t wsb, void* stp) {
     SelArgs a{x, col_mask, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
-              csc_ent, fired, total, overflow, dense_scratch, used_fallback, ws, wsb, as_stream(stp), Shard{1, 0, 0u, (uint32_t)F}, 0};
+              csc_ent, fired, total, overflow, dense_scratch, used_fallback, ws, wsb, as_stream(stp), Shard{1, 0, 0u, (uint32_t)F}, 0,
+              nullptr, 0.0f};
+    if (mode != 0 && !dense_scratch) return CLT_ERR_SHAPE;
     return run_stages(a, 0, 5);
 }
 
@@ -526,6 +545,10 @@ size_t clt_select_lists_exchange_info(int B, int L, int F, int k, int mode, int 
         case 3: return p.off_tie;                          // uint32 [world][tie_words]
         case 4: return p.tie_words;
         case 5: return 0;                                  // Head: word 0 = gate
+        case 6: return p.off_state;                        // SegState[S] (16-byte records): word 0 = key of the exact k-th value
+        case 7: return p.off_ckey;                         // candidate keys  [S][capS]
+        case 8: return p.off_cidx;                         // candidate flat indices [S][capS]
+        case 9: return p.capS;
         default: return 0;
     }
 }
@@ -540,7 +563,20 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
     if (f_off < 0 || f_off + F > F_global) return CLT_ERR_SHAPE;
     SelArgs a{x, col_mask, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
               csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
-              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, exhaustive};
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, exhaustive & 1, nullptr, 0.0f};
+    return run_stages(a, stage_lo, stage_hi);
+}
+
+int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, const uint32_t* prev_T,
+                             float margin, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
+                             uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
+                             float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
+                             int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
+    if (stage_lo < 0 || stage_hi > 5 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1 || !prev_T) return CLT_ERR_SHAPE;
+    if (f_off < 0 || f_off + F > F_global || !(margin > 0.0f && margin <= 1.0f)) return CLT_ERR_SHAPE;
+    SelArgs a{nullptr, nullptr, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
+              csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, 2, prev_T, margin};
     return run_stages(a, stage_lo, stage_hi);
 }
 }  // extern "C"

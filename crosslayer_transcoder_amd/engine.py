@@ -65,15 +65,27 @@ def _select_lists(nl, pre, col_mask=None, shard=None):
 
 
 class StepOutput(dict):
-    """Result of training_step.  In the sparse regime the dense `features` tensor is not part of the computation;
-    it is materialised from the lists on first access (tests, metric logging)."""
+    """Result of training_step.  In the sparse regime the dense `features` tensor is not part of the computation —
+    nor, when the encoder GEMM is fused with the selection, the pre-activations: both are materialised on first
+    access (tests, metric logging)."""
+
+    lazy = None
 
     def __missing__(self, key):
         if key == "features" and "lists" in self:
             S = self["lists"]
             self[key] = ops.sparse_scatter_dense(S, S.csc_val)
             return self[key]
+        if self.lazy and key in self.lazy:
+            self[key] = self.lazy[key]()
+            return self[key]
         raise KeyError(key)
+
+
+#: fuse the encoder GEMM with the BatchTopK candidate filter when last step's k-th value is known (bf16, base loss)
+FUSE_ENCODER_SELECT = True
+#: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
+SELECT_MARGIN = 0.9
 
 
 def _encoder_operand(enc):
@@ -248,15 +260,27 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
 
     xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, True, bf16)
     xo = xs16 if bf16 else xs32
-    pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
-
-    theta = None
-    feat = S = None
     shard = getattr(mod, "shard", None)
     if shard is not None and shard.world == 1:
         shard = None
-    if sparse:
+    theta = None
+    feat = S = pre = None
+    batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
+    if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
+            and getattr(nl, "_kth", None) is not None and d % 64 == 0 and F % 4 == 0):
+        mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
+        S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
+                                          nl.e, shard)
+        if S is not None:
+            nl._kth = kth
+    if S is None:
+        pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
+    if S is not None:
+        pass
+    elif sparse:
         S = _select_lists(nl, pre, shard=shard)
+        if batch_mode:
+            nl._kth = getattr(S, "kth", None)
     elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
@@ -284,7 +308,11 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if shard is not None:                     # features are split over ranks: count over all shards
         dead_cnt = shard.all_reduce_sum(dead_cnt.clone())
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
-    out = StepOutput(terms=terms, grads=grads, dead=dead, recons_norm=r, pre_actvs=pre)
+    out = StepOutput(terms=terms, grads=grads, dead=dead, recons_norm=r)
+    if pre is not None:
+        out["pre_actvs"] = pre
+    else:
+        out.lazy = {"pre_actvs": lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)}
     if feat is not None:
         out["features"] = feat
 
@@ -304,7 +332,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux, grads, optimizer)
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
-        db = torch.empty(L, F, dtype=torch.float32, device=pre.device)
+        db = torch.empty(L, F, dtype=torch.float32, device=xs32.device)
         Wt = enc.Wt
         kw = dict(colsum=db, second=(S2, dval2, xs32) if S2 is not None else None)
         if optimizer is not None:

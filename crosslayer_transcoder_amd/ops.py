@@ -10,7 +10,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from ._lib import call, lib
+from ._lib import CltError, call, lib
 
 _ws = {}
 
@@ -462,7 +462,7 @@ def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wei
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
     __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
-                 "csc_ent", "fired", "total", "overflow", "used_fallback")
+                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth")
 
 
 def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
@@ -534,6 +534,7 @@ def select_lists(x: torch.Tensor, k: int, mode: int, threshold: Optional[torch.T
          s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
          dense.data_ptr() if dense is not None else None, fb.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     s.used_fallback = fb
+    s.kth = selection_kth_keys(Bn, L, F, k, mode, x.device) if (mode != SELECT_ROWS and k > 0) else None
     return s
 
 
@@ -587,7 +588,69 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
     else:
         raise NotImplementedError("BatchTopK under feature sharding: more than 4096 values tied at the threshold on one shard")
     s.used_fallback = torch.full((1,), exhaustive, dtype=torch.int32, device=x.device)
+    s.kth = None
+    if k > 0:
+        o6 = lib.clt_select_lists_exchange_info(*dims, 6)
+        s.kth = ws[o6:o6 + 16 * S].view(torch.int32).view(S, 4)[:, 0].clone()
     return s
+
+
+def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor], k: int, mode: int, prev_T: torch.Tensor,
+                         margin: float, threshold: Optional[torch.Tensor], e: float, shard=None, cap: Optional[int] = None):
+    """Encoder forward fused with the BatchTopK / PerLayerBatchTopK selection: the bf16 NT GEMM's epilogue appends the
+    candidates (>= margin * last step's k-th value, `prev_T` int32 keys [S]) and the pre-activation tensor is never
+    written.  Returns (lists, T) — T = int32 keys [S] of this step's exact k-th values — or (None, None) when the
+    attempt was void (one host read) and the caller must run the ordinary GEMM + selection."""
+    from .parallel import run_sharded_selection
+    Bn, L, d = xs.shape
+    F = Wt.shape[1]
+    _chk(xs, torch.bfloat16); _chk(Wt, torch.bfloat16)
+    world, rank, f_off, Fg = (shard.world, shard.rank, shard.f_off, shard.F_global) if shard is not None else (1, 0, 0, F)
+    kglob = max(1, k * Bn * L)
+    if cap is None:
+        cap = kglob if world == 1 else min(kglob, 2 * kglob // world + 65536)
+    S = L if mode == SELECT_LAYER else 1
+    s = _empty_lists(Bn, L, F, cap, xs.device)
+    dims = (Bn, L, F, k, mode, world, 2)
+    ws = workspace(lib.clt_select_lists_sharded_workspace_bytes(*dims), xs.device)
+    off = [lib.clt_select_lists_exchange_info(*dims, w) for w in range(10)]
+    i32 = lambda o, n: ws[o:o + 4 * n].view(torch.int32)  # noqa: E731
+    exchange = {"lb": i32(off[0], 4 * S).view(S, 4), "hist": i32(off[1], off[2]),
+                "ties": i32(off[3], off[4] * world).view(world, off[4])}
+    fb = torch.zeros(1, dtype=torch.int32, device=xs.device)
+    base = ws.data_ptr()
+
+    def stages(lo, hi):
+        call("clt_select_lists_ext_f32", lo, hi, world, rank, f_off, Fg, prev_T.data_ptr(), float(margin), Bn, L, F, k, mode,
+             threshold.data_ptr() if threshold is not None else None, float(e or 0.0), s.cap, s.row_start.data_ptr(),
+             s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(),
+             s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), fb.data_ptr(), base,
+             ws.numel(), _stream())
+
+    def gemm():
+        rc = lib.clt_gemm_bf16_select(xs.data_ptr(), Wt.data_ptr(), Bn, F, d, L * d, d, L * F, L, d, d * F, F,
+                                      b.data_ptr() if b is not None else None, F, base + off[0], base + off[7], base + off[8],
+                                      off[9], int(mode == SELECT_LAYER), _stream())
+        if rc != 0:
+            raise CltError("clt_gemm_bf16_select", rc)
+
+    run_sharded_selection(stages, shard, S, exchange, after_stage0=gemm)
+    if int(fb) != 0:                               # the step's host read: did the bound from the last step hold?
+        return None, None
+    T = i32(off[6], 4 * S).view(S, 4)[:, 0].clone()
+    s.used_fallback = fb
+    s.kth = T
+    return s, T
+
+
+def selection_kth_keys(Bn, L, F, k, mode, device) -> torch.Tensor:
+    """int32 keys [S] of the exact k-th values left in the workspace by the last single-GPU ops.select_lists call
+    with these dimensions (valid when its fast path ran)."""
+    dims = (Bn, L, F, k, mode, 1, 0)
+    ws = workspace(lib.clt_select_lists_sharded_workspace_bytes(*dims), device)
+    S = L if mode == SELECT_LAYER else 1
+    o = lib.clt_select_lists_exchange_info(*dims, 6)
+    return ws[o:o + 16 * S].view(torch.int32).view(S, 4)[:, 0].clone()
 
 
 def select_rows_sharded(x: torch.Tensor, k: int, shard, col_mask: Optional[torch.Tensor] = None,

@@ -65,16 +65,22 @@ class FeatureShard:
         return t.narrow(dim, self.f_off, self.F_local)
 
 
-def run_sharded_selection(stages, shard: FeatureShard, S: int, exchange):
+def run_sharded_selection(stages, shard: Optional[FeatureShard], S: int, exchange, after_stage0=None):
     """Collective schedule of the sharded BatchTopK / PerLayerBatchTopK selection (include/clt_hip.h,
     clt_select_lists_sharded_f32).  `stages(lo, hi)` runs the local kernels of stages lo..hi; `exchange` maps
     "lb" -> int32 [S, 4] records (column 0 = lower-bound key), "hist" -> int32 [S*2048 + S], "ties" -> int32
     [world, tie_words] views of the selection workspace."""
     stages(0, 0)
-    lb = exchange["lb"]
-    keys = lb[:, 0].to(torch.int64) & 0xFFFFFFFF            # uint32 keys: order them as unsigned
-    shard.all_reduce_min(keys)
-    lb[:, 0] = (keys - (keys >= 2 ** 31).to(torch.int64) * 2 ** 32).to(torch.int32)      # back to the uint32 bit pattern
+    if after_stage0 is not None:             # fused encoder GEMM + filter: the bound is the same on every rank already
+        after_stage0()
+    elif shard is not None:
+        lb = exchange["lb"]
+        keys = lb[:, 0].to(torch.int64) & 0xFFFFFFFF            # uint32 keys: order them as unsigned
+        shard.all_reduce_min(keys)
+        lb[:, 0] = (keys - (keys >= 2 ** 31).to(torch.int64) * 2 ** 32).to(torch.int32)  # back to the uint32 bit pattern
+    if shard is None:                        # one GPU: no exchange points
+        stages(1, 5)
+        return
     for st in (1, 2, 3):
         stages(st, st)
         shard.all_reduce_sum(exchange["hist"])

@@ -215,6 +215,24 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
                                  float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                                  uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* Encoder GEMM fused with the candidate filter of the batch-mode selection (bf16 NT fast kernel only; returns 1 when
+ * the shape does not qualify): C = A[M][K] * B[N][K]^T + bias is NOT stored; every element whose key is >= the lower
+ * bound of its segment is appended to the candidate list of a selection workspace prepared by stage 0 of
+ * clt_select_lists_ext_f32.  ldc / sC define the flat index batch*sC + row*ldc + col of an element.
+ * ctl / cand_key / cand_idx / capS: workspace + clt_select_lists_exchange_info(..., flags = 2, which = 0 / 7 / 8 / 9). */
+int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, long ldc, int batch,
+                         long sA, long sB, long sC, const float* bias, long sBias, const uint32_t* ctl, uint32_t* cand_key,
+                         uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream);
+/* Batch-mode selection whose candidates come from clt_gemm_bf16_select.  The lower bound is margin * (the previous
+ * step's exact k-th value, prev_T[S] as order-preserving keys: word 0 of the SegState records, exchange info 6).
+ * Stage 0 prepares the workspace (then run the GEMM), stages 1..5 as clt_select_lists_sharded_f32 (workspace /
+ * exchange queries with flags = 2).  used_fallback[0] != 0: the attempt is void (bound too high, overflow, too many
+ * ties, previous value not positive): nothing was emitted, the caller runs the ordinary path. */
+int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, const uint32_t* prev_T,
+                             float margin, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
+                             uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
+                             float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
+                             int32_t* used_fallback, void* workspace, size_t ws_bytes, void* stream);
 /* Feature-sharded per-row TopK (mode 0 under sharding; k <= 2048): local top-k rows, then the exact global k-th value
  * of every row by 8 rounds of 4-bit radix counts.  Stages stage_lo..stage_hi with host collectives in between:
  *   after stages 0..7: SUM over ranks of the uint32 array at exchange offset 0 (length info 1 = rows*16)

@@ -187,3 +187,46 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
         gg = out["grads"][k].reshape(gref.shape).cpu()
         rel = (gg - gref).norm() / (gref.norm() + 1e-12)
         assert rel < 2e-2, f"{dec_kind}/{nl_kind} bf16 grad {k}: rel l2 err {rel:.3g}"
+
+
+@pytest.mark.parametrize("nl_kind", ["batchtopk", "perlayerbatchtopk"])
+def test_fused_encoder_select_equals_unfused(nl_kind):
+    """From the second step on the encoder GEMM appends the selection candidates in its epilogue (bound = 0.9 x last
+    step's k-th value) and no pre-activation tensor exists.  Same MFMA main loop => bit-identical pre-activations =>
+    the whole trajectory must equal the unfused path exactly; a void attempt (bound too high) falls back."""
+    import crosslayer_transcoder_amd.engine as E
+    from crosslayer_transcoder_amd import precision
+    from tests.build_cases import build_module
+    B, L, d, F = 512, 3, 128, 512
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(4)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    nl = {"kind": nl_kind, "k": 8, "e": 0.1}
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": nl, "loss": {"kind": "base"}}, "opt": {"lr": 1e-3},
+            "batches": torch.stack(batches), "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long),
+            "max_steps": 10}
+    results = {}
+    for fuse in (True, False):
+        E.FUSE_ENCODER_SELECT = fuse
+        try:
+            mod = build_module(case)
+            opt = mod.configure_optimizers()
+            losses, fused_steps = [], 0
+            with precision("bf16-mixed"):
+                for t, b in enumerate(batches):
+                    if fuse and t == 3:                               # poison the bound: the attempt must be void, not wrong
+                        mod.model.nonlinearity._kth = torch.full_like(mod.model.nonlinearity._kth, 0x4E6E6B28 - 2 ** 31)
+                    losses.append(float(mod.fused_train_step(b.cuda(), t, opt)))
+                    fused_steps += "pre_actvs" not in dict.keys(mod.last_step)
+            results[fuse] = (losses, {k: p.detach().clone() for k, p in mod.model.named_parameters()},
+                             mod.model.nonlinearity.threshold.clone(), fused_steps)
+        finally:
+            E.FUSE_ENCODER_SELECT = True
+    assert results[True][3] == 2 and results[False][3] == 0, "fused epilogue expected on steps 1 and 2 only"
+    assert results[True][0] == results[False][0]
+    assert torch.equal(results[True][2], results[False][2])
+    for k, p in results[True][1].items():
+        assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
