@@ -84,6 +84,7 @@ struct RowPassArgs {
     float* dot_out; float* dot_out2; long dot_stride, dot_stride2; int dot_slot_base;   // dot_out[slot*dot_stride + csc_pos]; slot_base < 0: slot = src layer - own layer
     float* colsum_out;           // optional: colsum_out[col] = sum coef (encoder bias gradient)
     float lr, omb1, b2, omb2, eps, wd, step_size, isb2; int adamw;
+    int src_bf16;                // src / src2 hold bf16 (uint16_t) elements instead of fp32: halves the gather traffic
 };
 
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
@@ -114,6 +115,22 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
             else wv[t][0] = a.W[ro + o];
         }
     }
+    // Adam moments: issued now so that they are in flight during the entry loop (used only after it)
+    float mm[NT][W], vv[NT][W];
+    if (!a.grad_out) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = cb + (t * 64 + lane) * W;
+#pragma unroll
+            for (int c = 0; c < W; ++c) { mm[t][c] = 0.0f; vv[t][c] = 0.0f; }
+            if (o < a.d) {
+                if (VEC) {
+                    const float4 x = *reinterpret_cast<const float4*>(a.m + ro + o); mm[t][0] = x.x; mm[t][1 % W] = x.y; mm[t][2 % W] = x.z; mm[t][3 % W] = x.w;
+                    const float4 y = *reinterpret_cast<const float4*>(a.v + ro + o); vv[t][0] = y.x; vv[t][1 % W] = y.y; vv[t][2 % W] = y.z; vv[t][3 % W] = y.w;
+                } else { mm[t][0] = a.m[ro + o]; vv[t][0] = a.v[ro + o]; }
+            }
+        }
+    }
     float csum = 0.0f;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -121,23 +138,29 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
         if (!cs) continue;
         const int32_t* tk = pass ? a.tok2 : a.tok;
         const float* cf = pass ? a.coef2 : a.coef;
-        const float* src = (pass ? a.src2 : a.src) + (long)layer * a.d;
+        const float* src = (pass ? a.src2 : a.src) + (a.src_bf16 ? 0 : (long)layer * a.d);
+        const uint16_t* srch = reinterpret_cast<const uint16_t*>(pass ? a.src2 : a.src) + (long)layer * a.d;
         float* dout = pass ? a.dot_out2 : a.dot_out;
         const long dstride = pass ? a.dot_stride2 : a.dot_stride;
         const uint32_t p0 = cs[col], p1 = cs[col + 1];
         for (uint32_t p = p0; p < p1; ++p) {
             const float cv = cf[p];
             const float* srow = src + (long)tk[p] * srs;
+            const uint16_t* srowh = srch + (long)tk[p] * srs;
             float dot = 0.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int o = cb + (t * 64 + lane) * W;
                 if (o < a.d) {
                     if (VEC) {
-                        const float4 s = *reinterpret_cast<const float4*>(srow + o);
+                        float4 s;
+                        if (a.src_bf16) {
+                            const ushort4 h = *reinterpret_cast<const ushort4*>(srowh + o);
+                            s = make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+                        } else s = *reinterpret_cast<const float4*>(srow + o);
                         g[t][0] += cv * s.x; g[t][1 % W] += cv * s.y; g[t][2 % W] += cv * s.z; g[t][3 % W] += cv * s.w;
                         dot += s.x * wv[t][0] + s.y * wv[t][1 % W] + s.z * wv[t][2 % W] + s.w * wv[t][3 % W];
-                    } else { const float s = srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
+                    } else { const float s = a.src_bf16 ? bf16_to_f32(srowh[o]) : srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
                 }
             }
             csum += cv;
@@ -172,28 +195,23 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
     for (int t = 0; t < NT; ++t) {
         const int o = cb + (t * 64 + lane) * W;
         if (o >= a.d) continue;
-        float mm[W], vv[W];
-        if (VEC) {
-            const float4 x = *reinterpret_cast<const float4*>(a.m + ro + o); mm[0] = x.x; mm[1 % W] = x.y; mm[2 % W] = x.z; mm[3 % W] = x.w;
-            const float4 y = *reinterpret_cast<const float4*>(a.v + ro + o); vv[0] = y.x; vv[1 % W] = y.y; vv[2 % W] = y.z; vv[3 % W] = y.w;
-        } else { mm[0] = a.m[ro + o]; vv[0] = a.v[ro + o]; }
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             float gg = g[t][c], pp = wv[t][c];
             if (a.wd != 0.0f) { if (a.adamw) pp *= (1.0f - a.lr * a.wd); else gg += a.wd * pp; }
-            mm[c] = mm[c] + (gg - mm[c]) * a.omb1;
-            vv[c] = vv[c] * a.b2 + a.omb2 * gg * gg;
-            pp -= a.step_size * (mm[c] / (sqrtf(vv[c]) * a.isb2 + a.eps));
+            mm[t][c] = mm[t][c] + (gg - mm[t][c]) * a.omb1;
+            vv[t][c] = vv[t][c] * a.b2 + a.omb2 * gg * gg;
+            pp -= a.step_size * (mm[t][c] / (sqrtf(vv[t][c]) * a.isb2 + a.eps));
             wv[t][c] = pp;
         }
         if (VEC) {
             *reinterpret_cast<float4*>(a.W + ro + o) = make_float4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
-            *reinterpret_cast<float4*>(a.m + ro + o) = make_float4(mm[0], mm[1 % W], mm[2 % W], mm[3 % W]);
-            *reinterpret_cast<float4*>(a.v + ro + o) = make_float4(vv[0], vv[1 % W], vv[2 % W], vv[3 % W]);
+            *reinterpret_cast<float4*>(a.m + ro + o) = make_float4(mm[t][0], mm[t][1 % W], mm[t][2 % W], mm[t][3 % W]);
+            *reinterpret_cast<float4*>(a.v + ro + o) = make_float4(vv[t][0], vv[t][1 % W], vv[t][2 % W], vv[t][3 % W]);
             if (a.shadow) { ushort4 h; h.x = f32_to_bf16(wv[t][0]); h.y = f32_to_bf16(wv[t][1 % W]); h.z = f32_to_bf16(wv[t][2 % W]); h.w = f32_to_bf16(wv[t][3 % W]);
                             *reinterpret_cast<ushort4*>(a.shadow + ro + o) = h; }
         } else {
-            a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[0]; a.v[ro + o] = vv[0];
+            a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[t][0]; a.v[ro + o] = vv[t][0];
             if (a.shadow) a.shadow[ro + o] = f32_to_bf16(wv[t][0]);
         }
     }
@@ -307,11 +325,13 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             const float* src2, float* dot_out, float* dot_out2, long dot_stride, long dot_stride2, int dot_slot,
                             float* colsum_out,
                             double lr,
-                            double beta1, double beta2, double eps, double weight_decay, int adamw, int step, void* stp) {
+                            double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
+                            void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
     RowPassArgs a;
     a.W = W; a.m = m; a.v = v; a.shadow = shadow; a.grad_out = grad_out; a.rows = rows; a.d = d; a.F = F; a.col0 = col0;
+    a.src_bf16 = src_bf16;
     a.src_layer = src_layer; a.L = L; a.col_start = col_start; a.tok = tok; a.coef = coef; a.src = src;
     a.col_start2 = col_start2; a.tok2 = tok2; a.coef2 = coef2; a.src2 = src2; a.dot_out = dot_out; a.dot_out2 = dot_out2; a.dot_stride = dot_stride; a.dot_stride2 = dot_stride2;
     a.dot_slot_base = dot_slot; a.colsum_out = colsum_out;
@@ -319,8 +339,8 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     const double bc1 = 1.0 - pow(beta1, s), bc2 = 1.0 - pow(beta2, s);
     a.lr = (float)lr; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
     a.wd = (float)weight_decay; a.step_size = (float)(lr / bc1); a.isb2 = (float)(1.0 / sqrt(bc2)); a.adamw = adamw;
-    const bool vec = d % 4 == 0 && aligned16(W) && aligned16(src) && (!m || aligned16(m)) && (!v || aligned16(v)) &&
-                     (!grad_out || aligned16(grad_out)) && (!src2 || aligned16(src2)) &&
+    const bool vec = d % 4 == 0 && aligned16(W) && (src_bf16 ? (reinterpret_cast<uintptr_t>(src) & 7) == 0 : aligned16(src)) && (!m || aligned16(m)) && (!v || aligned16(v)) &&
+                     (!grad_out || aligned16(grad_out)) && (!src2 || (src_bf16 ? (reinterpret_cast<uintptr_t>(src2) & 7) == 0 : aligned16(src2))) &&
                      (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
     hipStream_t st = as_stream(stp);
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);   // 64-lane iterations a whole row needs

@@ -210,6 +210,9 @@ class _Decoder:
         slots = self.L if self.clt else 1
         dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
         dots2 = torch.empty(slots, S2.cap, dtype=torch.float32, device=dev) if S2 is not None else None
+        if self.bf16:                      # bf16 mode: gathered g rows as bf16 (fp32 accumulate), half the gather bytes
+            g = ops.cast_bf16(g)
+            g2 = ops.cast_bf16(g2) if g2 is not None else None
         second = (S2, S2.csc_val, g2) if S2 is not None else None
         for l, (name, w) in enumerate(zip(self.names(), self.W32)):
             kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
@@ -334,7 +337,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
         db = torch.empty(L, F, dtype=torch.float32, device=xs32.device)
         Wt = enc.Wt
-        kw = dict(colsum=db, second=(S2, dval2, xs32) if S2 is not None else None)
+        xsrc = xs16 if bf16 else xs32
+        kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None)
         if optimizer is not None:
             kw.update(optimizer.begin_fused(enc.W, storage=Wt))
             if bf16:
@@ -343,7 +347,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             dWt = torch.empty_like(Wt)
             kw["grad_out"] = dWt
             grads["encoder.W"] = dWt.permute(0, 2, 1)
-        ops.sparse_row_pass(Wt, S, dval, xs32, 0, -1, **kw)
+        ops.sparse_row_pass(Wt, S, dval, xsrc, 0, -1, **kw)
         grads["encoder.b"] = db
         out["lists"] = S
         terms["loss"] = loss

@@ -706,18 +706,22 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
     per-entry dots go to `dots2` ([slots, lists2.cap])."""
-    _chk(W); _chk(coef); _chk(src)
+    _chk(W); _chk(coef)
+    src_bf16 = src.dtype == torch.bfloat16
+    _chk(src, src.dtype)
     d = W.shape[-1]
     rows = W.numel() // d
     a = adam or dict(lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False, step=1)
     s2, c2, x2 = second if second is not None else (None, None, None)
+    if x2 is not None and (x2.dtype == torch.bfloat16) != src_bf16:
+        raise TypeError("both gather sources must have the same dtype")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
+    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
          src_layer, s.col_start.data_ptr(), s.csc_tok.data_ptr(), coef.data_ptr(), src.data_ptr(),
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), _stream())
+         int(a["step"]), int(src_bf16), _stream())
 
 
 def sparse_reduce_dots(dots, s: SparseLists, cross_layer: bool):

@@ -258,13 +258,14 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  *   colsum_out[col] = sum_p coef[p]
  *   grad_out != NULL: grad is written there and nothing else is touched; otherwise the Adam/AdamW update
  *   (same semantics as clt_adam_f32) is applied to W, m, v in place (+ optional bf16 shadow of W).
- * layer = src_layer, or (col0 + r) / F when src_layer < 0; src tensors are [B][L][d] fp32. */
+ * layer = src_layer, or (col0 + r) / F when src_layer < 0; src tensors are [B][L][d] fp32, or bf16 (uint16_t) when
+ * src_bf16 != 0 (bf16 mode: halves the gather traffic; products still accumulate in fp32). */
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
                             const float* coef2, const float* src2, float* dot_out, float* dot_out2, long dot_stride,
                             long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, int adamw, int step, void* stream);
+                            double weight_decay, int adamw, int step, int src_bf16, void* stream);
 /* dval[p] = sum_{s < (cross_layer ? L - col/F : 1)} dots[s*stride + p]  — d(loss)/d(feature) per CSC entry. */
 int clt_sparse_reduce_dots_f32(const float* dots, long stride, const uint32_t* col_start, int L, int F,
                                int cross_layer, float* dval, void* stream);

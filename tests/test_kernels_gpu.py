@@ -348,6 +348,14 @@ def test_sparse_lists_and_decoder(ops, B, L, F, d, k):
         dfeat = ops.sparse_scatter_dense(S, dval).cpu()
         want = (rdf * (feat > 0)).float()
         assert_close(dfeat, want, **tol(want), what=f"sparse dfeat cross={cross}")
+        # bf16 gather source == fp32 source holding the bf16-rounded values, bit for bit
+        gh = g.to(torch.bfloat16)
+        dWa, dWb = torch.empty_like(Wd[-1]), torch.empty_like(Wd[-1])
+        da, db_ = torch.zeros(slots, cap, device=DEV), torch.zeros(slots, cap, device=DEV)
+        lsrc = (len(Wd) - 1) if cross else -1
+        ops.sparse_row_pass(Wd[-1], S, S.csc_val, gh.to(DEV), 0, lsrc, grad_out=dWa, dots=da, dot_slot=-1 if cross else 0)
+        ops.sparse_row_pass(Wd[-1], S, S.csc_val, gh.float().to(DEV), 0, lsrc, grad_out=dWb, dots=db_, dot_slot=-1 if cross else 0)
+        assert torch.equal(dWa, dWb) and torch.equal(da, db_)
         # fused Adam == gradient + clt_adam_f32 (same per-element arithmetic up to FMA contraction)
         w = Wd[-1]
         wa, wb = w.clone(), w.clone()
