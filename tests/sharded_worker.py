@@ -105,6 +105,49 @@ def gpu_selection_ties(rank, world):
                         f"layer k={k} ties={tie_heavy}"
 
 
+def gpu_bf16_fused_sharded(rank, world):
+    """bf16 mode under sharding, including the encoder GEMM fused with the candidate filter (steps >= 1): the sharded
+    run must track the unsharded run of the same full model (same per-element GEMM sums; only the all-reduce changes
+    the summation order of the reconstruction)."""
+    import copy
+    from crosslayer_transcoder_amd import precision
+    from crosslayer_transcoder_amd.parallel import FeatureShard, shard_module
+    from tests.build_cases import build_module
+    from tests.golden_cases import assert_close
+    B, L, d, F = 512, 3, 128, 1024
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(4)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    for kind in ("batchtopk", "perlayerbatchtopk"):
+        case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": kind, "k": 8, "e": 0.1},
+                        "loss": {"kind": "base"}}, "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
+                "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+        full = build_module(case, "cuda:0")
+        part = build_module(case, "cuda:0")
+        shard = FeatureShard(F)
+        shard_module(part, shard)
+        of, op = full.configure_optimizers(), part.configure_optimizers()
+        fused = 0
+        with precision("bf16-mixed"):
+            for t, b in enumerate(batches):
+                lf = full.fused_train_step(b.cuda(), t, of)
+                lp = part.fused_train_step(b.cuda(), t, op)
+                fused += "pre_actvs" not in dict.keys(part.last_step)
+                assert_close(lp, lf, 1e-5, 1e-7, f"{kind} loss step {t}")
+                want = shard.slice_features(full.last_step["features"], 2)
+                assert torch.equal(part.last_step["features"] > 0, want > 0), f"{kind}: active set differs at step {t}"
+        assert fused == 3, "the fused encoder+filter epilogue should run on steps 1..3"
+        assert_close(part.model.nonlinearity.threshold, full.model.nonlinearity.threshold, 1e-6, 0, "threshold")
+        fp = dict(full.model.named_parameters())
+        for k, p in part.model.named_parameters():
+            ax = feature_axis(k)
+            ref = fp[k] if ax is None else fp[k].narrow(ax, shard.f_off, shard.F_local)
+            assert_close(p, ref, 1e-4, 1e-6, f"{kind} param {k}")
+
+
 def sim_selection(rank, world):
     """torch restatement of the stage contract of clt_select_lists_sharded_f32 on one shard."""
     from crosslayer_transcoder_amd.parallel import FeatureShard, run_sharded_selection
@@ -214,6 +257,7 @@ def main():
         else:
             torch.cuda.set_device(0)
             gpu_selection_ties(rank, world)
+            gpu_bf16_fused_sharded(rank, world)
             for name in args.cases.split(","):
                 for fuse in (False, True):
                     gpu_case(name, fuse)
