@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--nonlinearity", default="batchtopk", choices=["batchtopk", "topk", "relu", "jumprelu"])
     ap.add_argument("--decoder", default="clt", choices=["clt", "plt"])
     ap.add_argument("--precision", default="bf16-mixed")
+    ap.add_argument("--ingest", default="resident", choices=["resident", "host"],
+                    help="host: every step's batch arrives as a pinned fp16 host tensor through the double-buffered "
+                         "H2D prefetcher (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -180,15 +183,22 @@ def main():
         torch.cuda.synchronize()
 
     from crosslayer_transcoder_amd import ops
+    feed = None
+    if args.ingest == "host":
+        import itertools
+        from crosslayer_transcoder_amd.data.prefetch import PinnedPrefetcher
+        host = [batch.to(torch.float16).cpu().pin_memory() for _ in range(2)]
+        feed = PinnedPrefetcher(itertools.cycle(host), device)
+    nxt = (lambda: next(feed)) if feed is not None else (lambda: batch)
     step = 0
     for _ in range(args.warmup):
-        mod.fused_train_step(batch, step, opt)
+        mod.fused_train_step(nxt(), step, opt)
         step += 1
     barrier()
     ops.TIMING = {}                 # HIP events around the dominant kernel's launches (recorded, not synced)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        mod.fused_train_step(batch, step, opt)
+        mod.fused_train_step(nxt(), step, opt)
         step += 1
     barrier()
     dt = time.perf_counter() - t0
@@ -210,7 +220,7 @@ def main():
                                + (f"(k={args.k})" if args.nonlinearity in ("batchtopk", "topk") else "")
                                + f" L={L} d={d} F={F}/layer B={args.batch}"
                                + (" +aux(k=512)" if args.aux else ""),
-                   "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU",
+                   "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU", "ingest": args.ingest,
                    "loss": float(mod.last_step["loss"])},
     }
     if rank == 0:

@@ -43,10 +43,9 @@ def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0"
     else:
         opt, sched = conf, None
     losses = []
-    for t, batch in enumerate(batches):
-        if t >= max_steps:
-            break
-        batch = batch.to(device, non_blocking=True)
+    from .data.prefetch import prefetch
+    import itertools
+    for t, batch in enumerate(prefetch(itertools.islice(batches, max_steps), device)):   # pinned, double-buffered H2D
         if fused:
             loss = module.fused_train_step(batch, t, opt, sched)
         else:

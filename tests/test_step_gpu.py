@@ -230,3 +230,24 @@ def test_fused_encoder_select_equals_unfused(nl_kind):
     assert torch.equal(results[True][2], results[False][2])
     for k, p in results[True][1].items():
         assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
+
+
+def test_pinned_prefetcher_and_fit_loop(golden):
+    """Batch ingest edge: double-buffered pinned H2D yields exactly the host batches (pinned and pageable sources, fp16
+    and fp32), and trainer.fit on the debug-cpu golden reproduces the reference loss curve through it."""
+    from crosslayer_transcoder_amd import trainer
+    from crosslayer_transcoder_amd.data.prefetch import PinnedPrefetcher
+    from tests.build_cases import build_module
+    g = torch.Generator().manual_seed(0)
+    for dtype, pin in ((torch.float16, True), (torch.float32, False)):
+        host = [torch.randn(64, 2, 3, 40, generator=g).to(dtype) for _ in range(7)]
+        src = [h.pin_memory() if pin else h for h in host]
+        got = []
+        for b in PinnedPrefetcher(src, "cuda:0", depth=2):
+            got.append((b * 1).cpu())                    # consume on the compute stream before the slot is reused
+        assert len(got) == 7 and all(torch.equal(a, h) for a, h in zip(got, host))
+    case = golden("dbg_jumprelu_clt")
+    mod = build_module(case)
+    losses, _ = trainer.fit(mod, list(case["batches"]), case["max_steps"])      # fewer batches than max_steps: stops early
+    for t, rec in enumerate(case["steps"]):
+        assert_close(losses[t], rec["loss"], 2e-5, 1e-7, f"fit loss {t}")
