@@ -22,31 +22,39 @@ __global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restric
     if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads, 4 consecutive items
+// per thread (one 16-byte load when aligned: a wave reads 1 KB contiguous), one barrier per 4096 items (the
+// per-wave totals are double buffered; the running carry lives in a register of every thread)
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ start,
                                                      uint32_t* __restrict__ total, uint8_t* __restrict__ fired, const int32_t* __restrict__ gate, int gate_on) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
-    __shared__ uint32_t sh[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    __shared__ uint32_t sh[2][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < n ? cnt[i] : 0u;
-        uint32_t inc = v;
+    const bool vec = (reinterpret_cast<uintptr_t>(cnt) & 15) == 0;
+    uint32_t carry = 0;
+    int par = 0;
+    for (long base = 0; base < n; base += 4096, par ^= 1) {
+        const long i0 = base + (long)threadIdx.x * 4;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (vec && i0 + 3 < n) { const uint4 t = *reinterpret_cast<const uint4*>(cnt + i0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (i0 + j < n) v[j] = cnt[i0 + j];
+        }
+        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) sh[w] = inc;
+        if (lane == 63) sh[par][w] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const uint32_t s = sh[k]; if (k < w) wbase += s; tot += s; }
-        const uint32_t c0 = carry;
-        if (i < n) { start[i] = c0 + wbase + inc - v; if (fired) fired[i] = v > 0; }
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c0 + tot;
-        __syncthreads();
+        for (int k = 0; k < 16; ++k) { const uint32_t s = sh[par][k]; if (k < w) wbase += s; tot += s; }
+        uint32_t run = carry + wbase + inc - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) { start[i0 + j] = run; if (fired) fired[i0 + j] = v[j] > 0; run += v[j]; }
+        carry += tot;
     }
     if (threadIdx.x == 0) { start[n] = carry; if (total) *total = carry; }
 }
