@@ -24,11 +24,12 @@ template <int NT, bool VEC>
 __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
                                                                  const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int L, int F,
-                                                                 int d, int cross_layer, uint32_t cap) {
+                                                                 int d, int cross_layer, uint32_t cap, int w_bf16) {
     constexpr int W = VEC ? 4 : 1;
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int l = L - 1 - w; l >= 0; l -= 4) {                 // heaviest layers first, 4 waves interleaved
         const float* Wl = Wptr[l];
+        const uint16_t* Wh = reinterpret_cast<const uint16_t*>(Wl);   // w_bf16: the table points at bf16 shadow rows
         const int lo = cross_layer ? 0 : l;
         const uint32_t e0 = row_start[(long)b * L + lo], e1 = min(row_start[(long)b * L + l + 1], cap);
         const int colsub = cross_layer ? 0 : l * F;            // per-layer decoder: W[l] rows are indexed by i only
@@ -46,14 +47,19 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
                 const int col = __shfl(mycol, j, 64) - colsub;
                 const float v = __shfl(myval, j, 64);
                 const float* row = Wl + (long)col * d;
+                const uint16_t* rowh = Wh + (long)col * d;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int o = (t * 64 + lane) * W;
                     if (o < d) {
                         if (VEC) {
-                            const float4 r = *reinterpret_cast<const float4*>(row + o);
+                            float4 r;
+                            if (w_bf16) {
+                                const ushort4 h = *reinterpret_cast<const ushort4*>(rowh + o);
+                                r = make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+                            } else r = *reinterpret_cast<const float4*>(row + o);
                             acc[t][0] += v * r.x; acc[t][1 % W] += v * r.y; acc[t][2 % W] += v * r.z; acc[t][3 % W] += v * r.w;
-                        } else acc[t][0] += v * row[o];
+                        } else acc[t][0] += v * (w_bf16 ? bf16_to_f32(rowh[o]) : row[o]);
                     }
                 }
             }
@@ -311,11 +317,11 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,
                                const float* bias, float* out, int B, int L, int F, int d, int cross_layer, uint32_t cap,
-                               void* stp) {
+                               int w_bf16, void* stp) {
     if (B <= 0 || L <= 0 || F <= 0 || d <= 0) return CLT_ERR_SHAPE;
     const bool vec = d % 4 == 0 && aligned16(out);
     DISPATCH_NT(sparse_decoder_fwd_kernel, dim3(B), as_stream(stp), d, vec, row_start, ent_col, ent_val, Wptr, bias, out, L, F, d,
-                cross_layer, cap);
+                cross_layer, cap, w_bf16);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 

@@ -109,9 +109,12 @@ class _Decoder:
     the k-contiguous "NT" form of the glds MFMA kernel, with transposed bf16 copies where the natural layout has
     the contraction index outermost (decoder forward: weights^T; weight gradients: features^T and g^T)."""
 
-    def __init__(self, dec, shard=None):
+    def __init__(self, dec, shard=None, shadow=False):
         self.dec = dec
         self.shard = shard
+        #: sparse regime, bf16 mode, Adam fused into the row pass: the gather forward reads bf16 shadow copies of the
+        #: decoder matrices that the same row pass keeps current (half the gathered bytes)
+        self.shadow = shadow
         self.clt = isinstance(dec, CrosslayerDecoder)
         self.L = dec.n_layers
         self.W32 = dec.weights()
@@ -190,18 +193,30 @@ class _Decoder:
             ops.rowscale_add(w, dn, sq, grads[f"decoder.W_{l}" if self.clt else "decoder.W"])
 
     # ---- sparse (list) passes -------------------------------------------------------------------
+    def shadows(self):
+        """bf16 copies of the decoder matrices, cast once and then refreshed by the fused Adam row pass; any other
+        in-place change of a weight (optimizer.step, load_state_dict) changes its version key and forces a re-cast."""
+        ver = [(w._version, getattr(w, "_clt_version", 0), w.data_ptr()) for w in self.W32]
+        cached = getattr(self.dec, "_bf16_shadows", None)
+        if cached is None or cached[0] != ver:
+            cached = (ver, [ops.cast_bf16(w.contiguous()) for w in self.W32])
+            self.dec._bf16_shadows = cached
+        return cached[1]
+
     def pointer_table(self):
         """Device array of the L per-target-layer weight base pointers (cached while storages are stable)."""
         d, F = self.dec.d_acts, self.dec.d_features
-        ptrs = [w.data_ptr() for w in self.W32] if self.clt else [self.W32[0].data_ptr() + 4 * l * F * d for l in range(self.L)]
-        cached = getattr(self.dec, "_wptr", None)
+        Ws, es, slot = (self.shadows(), 2, "_wptr_sh") if self.shadow else (self.W32, 4, "_wptr")
+        ptrs = [w.data_ptr() for w in Ws] if self.clt else [Ws[0].data_ptr() + es * l * F * d for l in range(self.L)]
+        cached = getattr(self.dec, slot, None)
         if cached is None or cached[0] != ptrs:
             cached = (ptrs, torch.tensor(ptrs, dtype=torch.int64).to(self.W32[0].device))
-            self.dec._wptr = cached
+            setattr(self.dec, slot, cached)
         return cached[1]
 
     def sparse_fwd(self, S):
-        return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt))
+        return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt,
+                                                   w_bf16=self.shadow))
 
     def sparse_bwd(self, S, g, S2, g2, grads, fused):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
@@ -218,6 +233,8 @@ class _Decoder:
             kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
             if fused is not None:
                 kw.update(fused.begin_fused(w))
+                if self.shadow:
+                    kw["shadow"] = self.shadows()[l]
             else:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
             ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
@@ -294,7 +311,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     else:
         raise NotImplementedError(f"fused step: unsupported nonlinearity {type(nl).__name__}")
 
-    D = _Decoder(dec, shard)
+    D = _Decoder(dec, shard, shadow=bool(sparse and bf16 and optimizer is not None))
     N = Bn * L * d
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"

@@ -692,11 +692,13 @@ def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
     return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(tensors[0].device)
 
 
-def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool):
+def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool,
+                       w_bf16: bool = False):
+    """wptr: device table of per-target-layer weight pointers (fp32 rows, or bf16 shadow rows when w_bf16)."""
     out = torch.empty(s.B, s.L, d, dtype=torch.float32, device=wptr.device)
     call("clt_sparse_decoder_fwd_f32", s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(),
          wptr.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), s.B, s.L, s.F, d,
-         int(cross_layer), s.cap, _stream())
+         int(cross_layer), s.cap, int(w_bf16), _stream())
     return out
 
 

@@ -127,7 +127,7 @@ def shard_module(mod, shard: FeatureShard):
                 nl.d_features = n
         mod.last_active = mod.last_active[:, f0:f0 + n].contiguous()
     for m in (enc, dec):
-        for attr in ("_bf16_shadow", "_wptr"):
+        for attr in ("_bf16_shadow", "_wptr", "_wptr_sh", "_bf16_shadows"):
             if hasattr(m, attr):
                 delattr(m, attr)
     mod.shard = shard

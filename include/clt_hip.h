@@ -247,10 +247,11 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
                                 size_t ws_bytes, void* stream);
 /* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
  * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
- * Wptr: DEVICE array of L device pointers. */
+ * Wptr: DEVICE array of L device pointers (to fp32 rows, or — w_bf16 != 0 — to the bf16 shadow copies that the
+ * Adam row pass maintains: half the gathered bytes in bf16 mode). */
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val,
                                const float* const* Wptr, const float* bias, float* out, int B, int L, int F, int d,
-                               int cross_layer, uint32_t cap, void* stream);
+                               int cross_layer, uint32_t cap, int w_bf16, void* stream);
 /* One streaming pass over `rows` weight rows W[r][0:d] (row r <-> CSC column col0 + r):
  *   grad[r,:]  = sum_{p in column} coef[p] * src[tok[p], layer, :]   (+ the same over the optional 2nd list)
  *   dot_out[slot*dot_stride + p] = src[tok[p], layer, :] . W[r,:]    (pre-update weights; dot_out2: the same for

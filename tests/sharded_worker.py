@@ -145,7 +145,9 @@ def gpu_bf16_fused_sharded(rank, world):
         for k, p in part.model.named_parameters():
             ax = feature_axis(k)
             ref = fp[k] if ax is None else fp[k].narrow(ax, shard.f_off, shard.F_local)
-            assert_close(p, ref, 1e-4, 1e-6, f"{kind} param {k}")
+            # Adam's first steps are sign-like: a bf16 rounding flip of one gathered g element moves a weight by a
+            # fraction of lr (same absolute allowance as the golden-trajectory tests: 0.3 * lr)
+            assert_close(p, ref, 1e-4, 0.3 * 1e-3, f"{kind} param {k}")
 
 
 def sim_selection(rank, world):

@@ -13,6 +13,10 @@ def _launch(extra, nproc=2, timeout=300):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", "29513", os.path.join(ROOT, "tests", "sharded_worker.py")] + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "sharded_worker_failure.log"), "w") as fh:
+            fh.write(p.stdout + "\n==== stderr ====\n" + p.stderr)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     assert p.stdout.count(": ok") == nproc
 
