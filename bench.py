@@ -63,6 +63,9 @@ def build(args, device, rank=0, world=1):
         with torch.no_grad():      # same init distribution as the full model (bounds depend on the GLOBAL feature count)
             mod.model.encoder.W.mul_((F / args.features) ** 0.5)
         mod.shard = FeatureShard(args.features)
+    elif args.shard_rehearsal:
+        from crosslayer_transcoder_amd.parallel import FeatureShard
+        mod.shard = FeatureShard(args.features, keep_single=True)
     return mod
 
 
@@ -151,6 +154,9 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "host"],
                     help="host: every step's batch arrives as a pinned fp16 host tensor through the double-buffered "
                          "H2D prefetcher (PCIe-inclusive rate; not the headline value)")
+    ap.add_argument("--shard-rehearsal", action="store_true",
+                    help="one rank, but run the feature-sharded schedule (every RCCL exchange point) anyway: measures the "
+                         "fixed cost the sharded step adds; not the headline value")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -170,6 +176,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif args.shard_rehearsal:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=device)
 
     import crosslayer_transcoder_amd as cta
     cta.set_precision(args.precision)
@@ -220,7 +229,8 @@ def main():
                                + (f"(k={args.k})" if args.nonlinearity in ("batchtopk", "topk") else "")
                                + f" L={L} d={d} F={F}/layer B={args.batch}"
                                + (" +aux(k=512)" if args.aux else ""),
-                   "parallelism": f"feature-shard x{world}" if world > 1 else "single GPU", "ingest": args.ingest,
+                   "parallelism": f"feature-shard x{world}" if world > 1 else
+                   ("single GPU, sharded schedule rehearsal" if args.shard_rehearsal else "single GPU"), "ingest": args.ingest,
                    "loss": float(mod.last_step["loss"])},
     }
     if rank == 0:

@@ -281,7 +281,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, True, bf16)
     xo = xs16 if bf16 else xs32
     shard = getattr(mod, "shard", None)
-    if shard is not None and shard.world == 1:
+    if shard is not None and shard.world == 1 and not shard.keep_single:
         shard = None
     theta = None
     feat = S = pre = None

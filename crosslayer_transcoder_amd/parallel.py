@@ -21,8 +21,12 @@ import torch.distributed as dist
 
 
 class FeatureShard:
-    def __init__(self, F_global: int, group=None, rank: Optional[int] = None, world: Optional[int] = None):
+    def __init__(self, F_global: int, group=None, rank: Optional[int] = None, world: Optional[int] = None,
+                 keep_single: bool = False):
         self.group = group
+        #: world == 1 normally drops to the unsharded step; keep_single runs the sharded schedule (all collectives)
+        #: on the single rank anyway — the way to exercise the RCCL path on a one-GPU box
+        self.keep_single = keep_single
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         if F_global % self.world:

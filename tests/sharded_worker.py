@@ -18,6 +18,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+KEEP_SINGLE = False          # --backend nccl with one rank: run the sharded schedule through RCCL anyway
+
 FEATURE_AXIS = {"encoder.W": 2, "encoder.b": 1, "nonlinearity.theta": 2, "decoder.W": 1}
 
 
@@ -35,7 +37,7 @@ def gpu_case(name, fuse_adam):
     case = load_golden(name)
     mod = build_module(case, "cuda:0")
     F = case["cfg"]["d_features"]
-    shard = FeatureShard(F)
+    shard = FeatureShard(F, keep_single=KEEP_SINGLE)
     shard_module(mod, shard)
     conf = mod.configure_optimizers()
     opt, sched = (conf["optimizer"], conf["lr_scheduler"]["scheduler"]) if isinstance(conf, dict) else (conf, None)
@@ -80,7 +82,7 @@ def gpu_selection_ties(rank, world):
     from oracle import clt_oracle as O
     g = torch.Generator().manual_seed(3)
     for B, L, F, ks in ((40, 3, 512, (1, 7, 100)), (9, 2, 64, (3, 40)), (33, 4, 256, (16,))):
-        shard = FeatureShard(F)
+        shard = FeatureShard(F, keep_single=KEEP_SINGLE)
         for tie_heavy in (True, False):
             # 24 distinct values: thousands of exact ties at every threshold, yet < 4096 per shard and segment (the
             # documented limit of the sharded batch modes; the per-row mode has no such limit)
@@ -127,7 +129,7 @@ def gpu_bf16_fused_sharded(rank, world):
                 "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
         full = build_module(case, "cuda:0")
         part = build_module(case, "cuda:0")
-        shard = FeatureShard(F)
+        shard = FeatureShard(F, keep_single=KEEP_SINGLE)
         shard_module(part, shard)
         of, op = full.configure_optimizers(), part.configure_optimizers()
         fused = 0
@@ -250,14 +252,22 @@ def main():
     ap.add_argument("--sim", action="store_true")
     ap.add_argument("--cases", default="batchtopk_clt_base,relu_clt_base,dbg_jumprelu_clt,jumprelu_plt_notanh,topk_clt_aux,"
                     "batchtopk_clt_aux,perlayerbatchtopk_clt_aux,topk_plt_aux_fewdead")
+    ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"])
     args = ap.parse_args()
-    dist.init_process_group("gloo")
+    global KEEP_SINGLE
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        KEEP_SINGLE = True
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
         if args.sim:
             sim_selection(rank, world)
         else:
-            torch.cuda.set_device(0)
+            if args.backend == "gloo":
+                torch.cuda.set_device(0)
             gpu_selection_ties(rank, world)
             gpu_bf16_fused_sharded(rank, world)
             for name in args.cases.split(","):

@@ -8,10 +8,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(extra, nproc=2, timeout=300):
+def _launch(extra, nproc=2, timeout=300, port=29513):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", "29513", os.path.join(ROOT, "tests", "sharded_worker.py")] + extra
+           "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py")] + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     if p.returncode != 0:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -32,3 +32,11 @@ def test_sharded_training_matches_reference_two_ranks():
     """Two ranks (sharing the GPU, gloo + host staging) each hold half of the features; every step equals the
     unsharded reference golden vectors slice by slice."""
     _launch([])
+
+
+@pytest.mark.gpu
+def test_sharded_schedule_through_rccl_single_rank():
+    """The same sharded schedule with backend "nccl" (RCCL) on one rank: every exchange point (int64 MIN, int32 SUM
+    on workspace views, all-gather into the tie region, fp64 / fp32 SUMs) goes through RCCL on its own stream, ordered
+    against the launch stream; results must still equal the reference goldens."""
+    _launch(["--backend", "nccl"], nproc=1, port=29517)
