@@ -11,6 +11,7 @@
 // All kernels are HBM/L2-bandwidth bound (row gathers of d floats); lists are ordered, so every sum has a
 // fixed order and results are bitwise reproducible.
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 #include "lists_common.h"
 
@@ -20,16 +21,21 @@ constexpr int TPB = 256;
 // ------------------------------------------------------------------------------------------------
 // forward gather: one wave per (token, target layer)
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool VEC>
+template <int NT, bool VEC, bool BF>
 __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
                                                                  const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int L, int F,
-                                                                 int d, int cross_layer, uint32_t cap, int w_bf16) {
+                                                                 int d, int cross_layer, uint32_t cap) {
     constexpr int W = VEC ? 4 : 1;
+    constexpr int U = NT <= 4 ? 4 : (NT <= 8 ? 2 : 1);         // entries in flight per wave (bounded by the register budget)
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int l = L - 1 - w; l >= 0; l -= 4) {                 // heaviest layers first, 4 waves interleaved
+    // target layers are dealt to the 4 waves heaviest first in serpentine order (a cross-layer target l gathers the
+    // entries of l + 1 source layers): 11,4,3 | 10,5,2 | 9,6,1 | 8,7,0 for L = 12
+    for (int rnd = 0; rnd * 4 < L; ++rnd) {
+        const int l = L - 1 - rnd * 4 - ((rnd & 1) ? 3 - w : w);
+        if (l < 0) continue;
         const float* Wl = Wptr[l];
-        const uint16_t* Wh = reinterpret_cast<const uint16_t*>(Wl);   // w_bf16: the table points at bf16 shadow rows
+        const uint16_t* Wh = reinterpret_cast<const uint16_t*>(Wl);   // BF: the table points at bf16 shadow rows
         const int lo = cross_layer ? 0 : l;
         const uint32_t e0 = row_start[(long)b * L + lo], e1 = min(row_start[(long)b * L + l + 1], cap);
         const int colsub = cross_layer ? 0 : l * F;            // per-layer decoder: W[l] rows are indexed by i only
@@ -40,27 +46,44 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
             for (int c = 0; c < W; ++c) { const int j = (t * 64 + lane) * W + c; acc[t][c] = (bias && j < d) ? bias[l * d + j] : 0.0f; }
         for (uint32_t base = e0; base < e1; base += 64) {
             const uint32_t mine = base + lane;
-            const int mycol = mine < e1 ? ent_col[mine] : 0;
+            // lanes past the end carry (row 0, value 0): the entry loop runs in whole groups of U without a tail
+            const int myrow = mine < e1 ? ent_col[mine] - colsub : 0;
             const float myval = mine < e1 ? ent_val[mine] : 0.0f;
             const int cnt = (int)min(64u, e1 - base);
-            for (int j = 0; j < cnt; ++j) {
-                const int col = __shfl(mycol, j, 64) - colsub;
-                const float v = __shfl(myval, j, 64);
-                const float* row = Wl + (long)col * d;
-                const uint16_t* rowh = Wh + (long)col * d;
+            for (int j = 0; j < cnt; j += U) {
+                float v[U]; long ro[U];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int o = (t * 64 + lane) * W;
-                    if (o < d) {
-                        if (VEC) {
-                            float4 r;
-                            if (w_bf16) {
-                                const ushort4 h = *reinterpret_cast<const ushort4*>(rowh + o);
-                                r = make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
-                            } else r = *reinterpret_cast<const float4*>(row + o);
-                            acc[t][0] += v * r.x; acc[t][1 % W] += v * r.y; acc[t][2 % W] += v * r.z; acc[t][3 % W] += v * r.w;
-                        } else acc[t][0] += v * (w_bf16 ? bf16_to_f32(rowh[o]) : row[o]);
-                    }
+                for (int u = 0; u < U; ++u) { ro[u] = (long)__shfl(myrow, j + u, 64) * d; v[u] = __shfl(myval, j + u, 64); }
+                if (VEC) {
+                    typedef typename std::conditional<BF, ushort4, float4>::type raw_t;    // converted at use: half the registers
+                    raw_t r[U][NT];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int o = (t * 64 + lane) * W;
+                            if (o < d) {
+                                if constexpr (BF) r[u][t] = *reinterpret_cast<const ushort4*>(Wh + ro[u] + o);
+                                else r[u][t] = *reinterpret_cast<const float4*>(Wl + ro[u] + o);
+                            } else r[u][t] = raw_t{};
+                        }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)            // entry order = list order: fixed summation order
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            float4 x;
+                            if constexpr (BF) x = make_float4(bf16_to_f32(r[u][t].x), bf16_to_f32(r[u][t].y), bf16_to_f32(r[u][t].z), bf16_to_f32(r[u][t].w));
+                            else x = r[u][t];
+                            acc[t][0] += v[u] * x.x; acc[t][1 % W] += v[u] * x.y; acc[t][2 % W] += v[u] * x.z; acc[t][3 % W] += v[u] * x.w;
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int o = t * 64 + lane;
+                            if (o < d) acc[t][0] += v[u] * (BF ? bf16_to_f32(Wh[ro[u] + o]) : Wl[ro[u] + o]);
+                        }
                 }
             }
         }
@@ -320,8 +343,23 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
                                int w_bf16, void* stp) {
     if (B <= 0 || L <= 0 || F <= 0 || d <= 0) return CLT_ERR_SHAPE;
     const bool vec = d % 4 == 0 && aligned16(out);
-    DISPATCH_NT(sparse_decoder_fwd_kernel, dim3(B), as_stream(stp), d, vec, row_start, ent_col, ent_val, Wptr, bias, out, L, F, d,
-                cross_layer, cap, w_bf16);
+#define FWDK(NT_, VEC_)                                                                                              \
+    do {                                                                                                              \
+        if (w_bf16) hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true>), dim3(B), dim3(TPB), 0, as_stream(stp),  \
+                                       row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap);      \
+        else hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, false>), dim3(B), dim3(TPB), 0, as_stream(stp), \
+                                row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap);             \
+    } while (0)
+    const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);
+    if (vec) {
+        if (chunks <= 1) FWDK(1, true); else if (chunks <= 2) FWDK(2, true); else if (chunks <= 3) FWDK(3, true);
+        else if (chunks <= 4) FWDK(4, true); else if (chunks <= 8) FWDK(8, true); else if (chunks <= 16) FWDK(16, true);
+        else return CLT_ERR_RANGE;
+    } else {
+        if (chunks <= 1) FWDK(1, false); else if (chunks <= 2) FWDK(2, false); else if (chunks <= 4) FWDK(4, false);
+        else if (chunks <= 16) FWDK(16, false); else return CLT_ERR_RANGE;
+    }
+#undef FWDK
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
