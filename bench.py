@@ -101,7 +101,7 @@ def roofline(timing, mod, args):
     """Dominant kernel = row_pass_kernel (sparse weight gradient + feature-gradient dots + Adam in one streaming
     pass over a weight matrix; 13 launches per step: 12 decoder matrices W_l + the encoder).  HBM-bound.
     Algorithmic bytes of a launch over `rows` weight rows of d floats whose CSC columns hold `hits` entries:
-        24*rows*d  (W, m, v read + written, fp32)  [+ 2*rows*d for the bf16 shadow of the encoder weight]
+        24*rows*d  (W, m, v read + written, fp32)  [+ 2*rows*d where the pass also writes the weight's bf16 shadow]
       + hits*(e*d + 12)  (one gathered source row g[tok,l,:] or xs[tok,l,:] of e-byte elements — bf16 in bf16 mode —,
                           token id, coefficient, dot result)
       + 4*rows  (column offsets)
@@ -121,9 +121,9 @@ def roofline(timing, mod, args):
     col_start = lists.col_start.cpu().long()
     bf16 = args.precision.startswith("bf16")
     nbytes = ms = 0.0
-    for e0, e1, (rows, d, col0, src_layer, fused, src_bytes) in ev:
+    for e0, e1, (rows, d, col0, src_layer, fused, src_bytes, shadow) in ev:
         hits = int(col_start[col0 + rows] - col_start[col0])
-        per_row = (24 if fused else 4) * d + ((2 * d) if (bf16 and src_layer < 0 and fused) else 0) + 4
+        per_row = (24 if fused else 4) * d + (2 * d if shadow else 0) + 4
         nbytes += rows * per_row + hits * (src_bytes * d + 12)
         ms += e0.elapsed_time(e1)
     ach = nbytes / (ms * 1e-3) / 1e9

@@ -54,7 +54,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
     }
-    const int ta = lid % tilesA, tb = lid / tilesA;
+    // tile order inside an XCD's contiguous range: panels of GA = 4 A-tiles, B-tile index next, A-tile fastest — the 32
+    // blocks an XCD runs together form a 4 x 8 patch (12 distinct operand tiles per k-step instead of 18), and the
+    // panel's A rows (4 x 256 rows x K bf16, 1.5 MB at K = 768) stay in the XCD's 4 MB L2 while the B tiles stream
+    // (8192^3: 927 -> 1006 TFLOP/s)
+    int ta, tb;
+    {
+        constexpr int GA = 4;
+        const int full = tilesA / GA, rem = tilesA - full * GA, per = GA * tilesB;
+        if (lid < full * per) { const int pn = lid / per, r = lid - pn * per; tb = r / GA; ta = pn * GA + (r - tb * GA); }
+        else { const int r = lid - full * per; tb = r / rem; ta = full * GA + (r - tb * rem); }
+    }
     const int a0 = ta * TA, b0 = tb * TB;
     A += (long)batch * sA; B += (long)batch * sB;
     if (EPI == 0) C += (long)batch * sC;

@@ -718,7 +718,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
     if x2 is not None and (x2.dtype == torch.bfloat16) != src_bf16:
         raise TypeError("both gather sources must have the same dtype")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
+    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4, shadow is not None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
          src_layer, s.col_start.data_ptr(), s.csc_tok.data_ptr(), coef.data_ptr(), src.data_ptr(),
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
