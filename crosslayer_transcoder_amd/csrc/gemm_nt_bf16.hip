@@ -21,8 +21,13 @@ constexpr int TB = 256, TA = 256, TK = 64;              // tile: B rows (C colum
 constexpr int OP_BYTES = 256 * TK * 2;                  // one operand tile in LDS (32 KiB)
 constexpr int STAGE_BYTES = 2 * OP_BYTES;               // B tile | A tile
 constexpr int EROW = 512 + 16;                          // epilogue transposition: padded row of 128 floats
-constexpr int LDS_BYTES = 8 * 32 * EROW;                // max(double-buffered staging 128 KiB, epilogue 132 KiB)
-static_assert(LDS_BYTES >= 2 * STAGE_BYTES, "LDS");
+constexpr int ESTG = 2048;                              // select epilogue: block-level candidate staging entries
+// LDS map: [0, 64 KiB) staging buffer 0 | [64, 128 KiB) staging buffer 1 | epilogue scratch.  The epilogue of a tile runs
+// while buffer 0 already receives the next tile's first k-tile, so its scratch starts at 64 KiB (store epilogue:
+// 8 waves x 16 rows x 528 B = 66 KiB) or above both buffers (select epilogue: key/index staging, 16 KiB + counters).
+constexpr int EPI_BASE_STORE = STAGE_BYTES, EPI_BASE_SELECT = 2 * STAGE_BYTES;
+constexpr int LDS_BYTES = EPI_BASE_SELECT + ESTG * 8 + 64;
+static_assert(EPI_BASE_STORE + 8 * 16 * EROW <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
 
@@ -37,51 +42,57 @@ struct SelEpi {
     uint32_t* cand_key; uint32_t* cand_idx; uint32_t capS;
     int seg_per_batch;            // 1: segment = batch index (per-layer selection); 0: one segment
 };
-constexpr int ESTG = 2048;       // block-level candidate staging entries in LDS
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
-                                                           float* __restrict__ C, int M, int N, int K, long lda, long ldb,
-                                                           long ldc, long sA, long sB, long sC, const float* __restrict__ bias,
-                                                           long sBias, int accumulate, int tilesA, int tilesB, int diag, SelEpi se) {
+__global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
+                                                           float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
+                                                           long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
+                                                           long sBias, int accumulate, int tilesA, int tilesB, int total, int diag,
+                                                           SelEpi se) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
-    // ---- block -> (batch, tile) with an XCD-aware, bijective remap ------------------------------------
     const int nwg = tilesA * tilesB;
-    const int batch = blockIdx.x / nwg;
-    int lid = blockIdx.x - batch * nwg;
-    {
-        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
-    }
-    // tile order inside an XCD's contiguous range: panels of GA = 4 A-tiles, B-tile index next, A-tile fastest — the 32
-    // blocks an XCD runs together form a 4 x 8 patch (12 distinct operand tiles per k-step instead of 18), and the
-    // panel's A rows (4 x 256 rows x K bf16, 1.5 MB at K = 768) stay in the XCD's 4 MB L2 while the B tiles stream
-    // (8192^3: 927 -> 1006 TFLOP/s)
-    int ta, tb;
-    {
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- virtual block -> (batch, tile) with an XCD-aware, bijective remap -----------------------------
+    // The grid is persistent (one block per CU, a multiple of 8): block p walks the virtual blocks p, p + G, ...,
+    // so vb & 7 is the block's XCD for every tile it processes.
+    struct Tile { int batch, a0, b0; };
+    auto decode = [&](int vb) {
+        Tile t;
+        t.batch = vb / nwg;
+        int lid = vb - t.batch * nwg;
+        {
+            const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
+            lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+        }
+        // tile order inside an XCD's contiguous range: panels of GA = 4 A-tiles, B-tile index next, A-tile fastest — the
+        // 32 blocks an XCD runs together form a 4 x 8 patch (12 distinct operand tiles per k-step instead of 18), and
+        // the panel's A rows (4 x 256 rows x K bf16, 1.5 MB at K = 768) stay in the XCD's 4 MB L2 while the B tiles
+        // stream (8192^3: 927 -> 1006 TFLOP/s)
+        int ta, tb;
         constexpr int GA = 4;
         const int full = tilesA / GA, rem = tilesA - full * GA, per = GA * tilesB;
         if (lid < full * per) { const int pn = lid / per, r = lid - pn * per; tb = r / GA; ta = pn * GA + (r - tb * GA); }
         else { const int r = lid - full * per; tb = r / rem; ta = full * GA + (r - tb * rem); }
-    }
-    const int a0 = ta * TA, b0 = tb * TB;
-    A += (long)batch * sA; B += (long)batch * sB;
-    if (EPI == 0) C += (long)batch * sC;
-    if (bias) bias += (long)batch * sBias;
+        t.a0 = ta * TA; t.b0 = tb * TB;
+        return t;
+    };
 
     // ---- staging addresses: per glds instruction a wave fills 8 rows x 128 B ---------------------------
     const uint16_t* gB[4];
     const uint16_t* gA[4];
+    auto aim = [&](const Tile& t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 8 + w) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);           // logical k-chunk stored at this physical slot
-        int rb = b0 + row; rb = rb < N ? rb : N - 1;               // clamp: rows past the edge are loaded, never stored
-        int ra = a0 + row; ra = ra < M ? ra : M - 1;
-        gB[i] = B + (long)rb * ldb + chunk * 8;
-        gA[i] = A + (long)ra * lda + chunk * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + w) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);       // logical k-chunk stored at this physical slot
+            int rb = t.b0 + row; rb = rb < N ? rb : N - 1;         // clamp: rows past the edge are loaded, never stored
+            int ra = t.a0 + row; ra = ra < M ? ra : M - 1;
+            gB[i] = B0 + (long)t.batch * sB + (long)rb * ldb + chunk * 8;
+            gA[i] = A0 + (long)t.batch * sA + (long)ra * lda + chunk * 8;
+        }
+    };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
 #pragma unroll
@@ -91,7 +102,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     };
 
     // ---- fragment read offsets (bytes inside an operand tile) ------------------------------------------
-    const int fr = lane & 15, fq = lane >> 4;
     int offB[2], offA[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -99,144 +109,165 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         offB[ks] = (wm * 128 + fr) * 128 + phys * 16;
         offA[ks] = OP_BYTES + (wn * 64 + fr) * 128 + phys * 16;
     }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
     const int nk = (diag & 2) ? 0 : K / TK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const unsigned char* base = nt_smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fb[8], fa[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) fa[n] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + n * 2048);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) fb[m] = *reinterpret_cast<const bf16x8*>(base + offB[ks] + m * 2048);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[n], acc[m][n], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
 
-    if (EPI == 1) {
-        // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
-        uint32_t* skey = reinterpret_cast<uint32_t*>(nt_smem);
-        uint32_t* sidx = skey + ESTG;
-        uint32_t* scnt = sidx + ESTG;                     // [0] staged count, [1] global base
-        const int seg = se.seg_per_batch ? batch : 0;
-        uint32_t* gcnt = const_cast<uint32_t*>(se.ctl) + 4 * seg + 1;
-        const uint32_t lb = se.ctl[4 * seg];
-        uint32_t* ck = se.cand_key + (size_t)seg * se.capS;
-        uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
-        if (tid == 0) scnt[0] = 0;
+    int vb = blockIdx.x;
+    Tile t = decode(vb);
+    aim(t);
+    stage(0, 0);
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first k-tile (staged before the previous tile's epilogue)
         __syncthreads();
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const float lbf = key_f32(lb);                    // fast reject in float: !(v < lbf) also lets NaNs through
-        f32x4 bv[8];
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const unsigned char* base = nt_smem + cur * STAGE_BYTES;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int col = b0 + wm * 128 + m * 16 + fq * 4;
-            bv[m] = (bias && col < N) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fb[8], fa[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) fa[n] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + n * 2048);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) fb[m] = *reinterpret_cast<const bf16x8*>(base + offB[ks] + m * 2048);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int row = a0 + wn * 64 + n * 16 + fr;
-            const uint32_t flat_row = (uint32_t)((long)batch * sC + (long)row * ldc);
+        // Both staging buffers are idle now (the trailing barrier retired every read).  The next tile's first k-tile
+        // goes into buffer 0 while this tile's epilogue runs out of the LDS above it.
+        const Tile cur = t;
+        const int nvb = vb + (int)gridDim.x;
+        const bool more = nvb < total;
+        if (more) { t = decode(nvb); aim(t); stage(0, 0); }
+        const int batch = cur.batch, a0 = cur.a0, b0 = cur.b0;
+        const float* bias = bias0 ? bias0 + (long)batch * sBias : nullptr;
+
+        if (EPI == 1) {
+            // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
+            uint32_t* skey = reinterpret_cast<uint32_t*>(nt_smem + EPI_BASE_SELECT);
+            uint32_t* sidx = skey + ESTG;
+            uint32_t* scnt = sidx + ESTG;                     // [0] staged count, [1] global base
+            const int seg = se.seg_per_batch ? batch : 0;
+            uint32_t* gcnt = const_cast<uint32_t*>(se.ctl) + 4 * seg + 1;
+            const uint32_t lb = se.ctl[4 * seg];
+            uint32_t* ck = se.cand_key + (size_t)seg * se.capS;
+            uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
+            if (tid == 0) scnt[0] = 0;
+            __syncthreads();
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const float lbf = key_f32(lb);                    // fast reject in float: !(v < lbf) also lets NaNs through
+            f32x4 bv[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int col = b0 + wm * 128 + m * 16 + fq * 4;
-                const f32x4 v = acc[m][n] + bv[m];
-                const bool in = row < M && col < N;
-                const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
-                if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
-                uint32_t key[4]; bool pr[4]; unsigned long long bm[4]; uint32_t tot = 0;
+                bv[m] = (bias && col < N) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    key[c] = f32_key(v[c]);
-                    pr[c] = in && key[c] >= lb;
-                    bm[c] = __ballot(pr[c]);
-                    tot += (uint32_t)__popcll(bm[c]);
-                }
-                if (tot == 0) continue;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&scnt[0], tot);
-                base = __shfl(base, 0, 64);
-                uint32_t off = base;
+            for (int n = 0; n < 4; ++n) {
+                const int row = a0 + wn * 64 + n * 16 + fr;
+                const uint32_t flat_row = (uint32_t)((long)batch * sC + (long)row * ldc);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) off += (uint32_t)__popcll(bm[c] & lt);
+                for (int m = 0; m < 8; ++m) {
+                    const int col = b0 + wm * 128 + m * 16 + fq * 4;
+                    const f32x4 v = acc[m][n] + bv[m];
+                    const bool in = row < M && col < N;
+                    const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
+                    if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
+                    uint32_t key[4]; bool pr[4]; unsigned long long bm[4]; uint32_t tot = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (pr[c]) {
-                        const uint32_t fi = flat_row + (uint32_t)(col + c);
-                        if (off < (uint32_t)ESTG) { skey[off] = key[c]; sidx[off] = fi; }
-                        else {                               // staging full (pathological tile): straight to the global list
-                            const uint32_t pos = atomicAdd(gcnt, 1u);
-                            if (pos < se.capS) { ck[pos] = key[c]; ci[pos] = fi; }
-                        }
-                        ++off;
+                    for (int c = 0; c < 4; ++c) {
+                        key[c] = f32_key(v[c]);
+                        pr[c] = in && key[c] >= lb;
+                        bm[c] = __ballot(pr[c]);
+                        tot += (uint32_t)__popcll(bm[c]);
                     }
+                    if (tot == 0) continue;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&scnt[0], tot);
+                    base = __shfl(base, 0, 64);
+                    uint32_t off = base;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) off += (uint32_t)__popcll(bm[c] & lt);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (pr[c]) {
+                            const uint32_t fi = flat_row + (uint32_t)(col + c);
+                            if (off < (uint32_t)ESTG) { skey[off] = key[c]; sidx[off] = fi; }
+                            else {                               // staging full (pathological tile): straight to the global list
+                                const uint32_t pos = atomicAdd(gcnt, 1u);
+                                if (pos < se.capS) { ck[pos] = key[c]; ci[pos] = fi; }
+                            }
+                            ++off;
+                        }
+                }
+            }
+            __syncthreads();
+            const uint32_t staged = min(scnt[0], (uint32_t)ESTG);
+            if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
+            __syncthreads();
+            const uint32_t gbase = scnt[1];
+            for (uint32_t i = tid; i < staged; i += 512) {
+                const uint32_t pos = gbase + i;
+                if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
+            }
+        } else {
+            // ---- store epilogue -------------------------------------------------------------------------------
+            // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
+            // transposes its 64 x 128 sub-tile through a private LDS region (four passes of 16 rows, 528-byte padded
+            // rows: conflict-free b128 writes) and stores 512-byte contiguous row segments: 2 rows per wave-instruction.
+            float* C = C0 + (long)batch * sC;
+            unsigned char* ebuf = nt_smem + EPI_BASE_STORE + w * (16 * EROW);
+            const int er = lane >> 5, ec = (lane & 31) * 4;
+            const int col = b0 + wm * 128 + ec;
+            f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    *reinterpret_cast<f32x4*>(ebuf + fr * EROW + (m * 16 + fq * 4) * 4) = acc[m][n];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 2 + er;
+                    const int row = a0 + wn * 64 + n * 16 + lr;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4);
+                    if (row < M && col < N) {
+                        float* dst = C + (long)row * ldc + col;
+                        v += bv;
+                        if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); v += old; }
+                        if (diag & 1) { asm volatile("" ::"v"(v)); } else *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
-        const uint32_t staged = min(scnt[0], (uint32_t)ESTG);
-        if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
-        __syncthreads();
-        const uint32_t gbase = scnt[1];
-        for (uint32_t i = tid; i < staged; i += 512) {
-            const uint32_t pos = gbase + i;
-            if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
-        }
-        return;
+        if (!more) break;
+        vb = nvb;
     }
+}
 
-    // ---- epilogue ---------------------------------------------------------------------------------------
-    // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
-    // transposes its 64 x 128 sub-tile through a private LDS region (two halves of 32 rows, 528-byte padded rows:
-    // conflict-free b128 writes) and stores 512-byte contiguous row segments: 2 rows per wave-instruction.
-    // (The last K-step's trailing barrier has retired every read of the staging buffers.)
-    unsigned char* ebuf = nt_smem + w * (32 * EROW);
-    const int er = lane >> 5, ec = (lane & 31) * 4;
-    const int colw = b0 + wm * 128;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-                *reinterpret_cast<f32x4*>(ebuf + (n2 * 16 + fr) * EROW + (m * 16 + fq * 4) * 4) = acc[m][h * 2 + n2];
-        __builtin_amdgcn_wave_barrier();
-        const int col = colw + ec;
-        f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (bias && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int lr = it * 2 + er;
-            const int row = a0 + wn * 64 + h * 32 + lr;
-            f32x4 v = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4);
-            if (row < M && col < N) {
-                float* dst = C + (long)row * ldc + col;
-                v += bv;
-                if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); v += old; }
-                if (diag & 1) { asm volatile("" ::"v"(v)); } else *reinterpret_cast<f32x4*>(dst) = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+// persistent grid: one block per CU (a multiple of 8, so that a block keeps its XCD over all its tiles)
+int persistent_grid(long nblk) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) cus = 256;
+        else cus = pr.multiProcessorCount >= 8 ? pr.multiProcessorCount / 8 * 8 : 8;
     }
+    return (int)(nblk < cus ? nblk : cus);
 }
 }  // namespace
 
@@ -254,9 +285,9 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     if (nblk > 0x7fffffffL) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)nblk), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, ldc, sA,
-                       sB, sC, bias, sBias, accumulate, tilesA, tilesB, getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0,
-                       SelEpi{});
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
+                       lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
+                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{});
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
@@ -276,9 +307,9 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
     if (nblk > 0x7fffffffL) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)nblk), dim3(512), LDS_BYTES, as_stream(stream), A, B, (float*)nullptr, M,
-                       N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, 0, SelEpi{ctl, cand_key, cand_idx, capS,
-                       seg_per_batch});
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
+                       (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, 0,
+                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch});
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
