@@ -304,6 +304,147 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
         if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = f32_to_bf16(tile[tx][c]);
 }
 
+// ---- fused tile passes of the dense bf16 regime (JumpReLU / ReLU modules) ---------------------------------------
+// The dense step needs the feature matrix twice as a bf16 GEMM operand — [tokens][L*F] for the decoder forward and
+// transposed [L*F][tokens] for the decoder weight gradient — and the same for d(loss)/d(pre-activations) of the
+// encoder weight gradient.  These kernels read the fp32 pre-activations ONCE per direction and write the bf16 operands
+// directly (no fp32 feature / dpre tensor, no separate cast, transpose, column-sum or any-positive passes).
+// Tile: 64 rows (tokens) x 256 columns; a thread owns 4 consecutive columns of rows w, w+4, ...; the transposed copy goes
+// through LDS (row pitch 129 dwords: conflict-free b32 stores, 32 distinct banks per transposed u16 read instruction).
+constexpr int FT_R = 64, FT_C = 256, FT_PITCH = 258;      // pitch in bf16 elements (= 129 dwords)
+
+__device__ __forceinline__ void ft_store_row(uint16_t (*tile)[FT_PITCH], int r, int tx, const uint16_t h[4]) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(&tile[r][4 * tx]);
+    p[0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    p[1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+}
+// transposed write-out of a [64][256] bf16 tile: column c gets 64 consecutive rows (128 B); 8 threads x 16 B per column
+__device__ __forceinline__ void ft_write_transposed(const uint16_t (*tile)[FT_PITCH], uint16_t* __restrict__ outT, long c0, int r0,
+                                                    int rows, int n) {
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + threadIdx.x, c = idx >> 3, rg = idx & 7;
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = (uint32_t)tile[rg * 8 + 2 * j][c] | ((uint32_t)tile[rg * 8 + 2 * j + 1][c] << 16);
+        if (c0 + c < n && r0 + rg * 8 < rows)
+            *reinterpret_cast<uint4*>(outT + (c0 + c) * (long)rows + r0 + rg * 8) = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+// grid (ceil(n/256), ceil(rows/64)); rows % 8 == 0, n % 4 == 0
+__global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ theta, int rows,
+                                                                int n, uint16_t* __restrict__ feat, uint16_t* __restrict__ featT,
+                                                                uint8_t* __restrict__ fired) {
+    __shared__ uint16_t tile[FT_R][FT_PITCH];
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long c0 = (long)blockIdx.x * FT_C;
+    const int r0 = blockIdx.y * FT_R;
+    const long col = c0 + 4 * tx;
+    const bool cin = col < n;
+    float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (theta && cin) th = *reinterpret_cast<const float4*>(theta + col);
+    bool any[4] = {false, false, false, false};
+    for (int i = 0; i < 16; ++i) {
+        const int r = w + 4 * i, row = r0 + r;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool in = cin && row < rows;
+        if (in) v = *reinterpret_cast<const float4*>(x + (long)row * n + col);
+        const float f[4] = {(v.x > th.x && v.x > 0.0f) ? v.x : v.x * 0.0f, (v.y > th.y && v.y > 0.0f) ? v.y : v.y * 0.0f,
+                            (v.z > th.z && v.z > 0.0f) ? v.z : v.z * 0.0f, (v.w > th.w && v.w > 0.0f) ? v.w : v.w * 0.0f};
+        uint16_t h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = f32_to_bf16(f[k]); any[k] |= f[k] > 0.0f; }
+        if (in) *reinterpret_cast<uint2*>(feat + (long)row * n + col) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        ft_store_row(tile, r, tx, h);
+    }
+    if (cin) {                                         // fired[] is zeroed by the host wrapper; equal-value stores may race
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (any[k]) fired[col + k] = 1;
+    }
+    __syncthreads();
+    ft_write_transposed(tile, featT, c0, r0, rows, n);
+}
+
+// grid (ceil(n/256), ceil(rows/256)): a block walks 4 row tiles of its 256 columns, keeping the column partial sums in
+// registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
+__global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const float* __restrict__ x, const float* __restrict__ theta,
+                                                                 const float* __restrict__ sq, const float* __restrict__ dfm, float bw,
+                                                                 float lamB, float c, int use_tanh, float coefBL,
+                                                                 uint16_t* __restrict__ dpreT, float* __restrict__ part,
+                                                                 double* __restrict__ part_s, int rows, int n) {
+    __shared__ uint16_t tile[FT_R][FT_PITCH];
+    __shared__ float red[3][4][FT_C];
+    __shared__ double sh[4];
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long c0 = (long)blockIdx.x * FT_C;
+    const long col = c0 + 4 * tx;
+    const bool cin = col < n;
+    float th[4] = {0, 0, 0, 0}, nrm[4] = {0, 0, 0, 0}, thc[4];
+    if (cin) {
+        const float4 t4 = *reinterpret_cast<const float4*>(theta + col), s4 = *reinterpret_cast<const float4*>(sq + col);
+        th[0] = t4.x; th[1] = t4.y; th[2] = t4.z; th[3] = t4.w;
+        nrm[0] = sqrtf(s4.x); nrm[1] = sqrtf(s4.y); nrm[2] = sqrtf(s4.z); nrm[3] = sqrtf(s4.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) thc[k] = -(th[k] / bw);
+    float a_th[4] = {0, 0, 0, 0}, a_dn[4] = {0, 0, 0, 0}, a_db[4] = {0, 0, 0, 0};
+    double s_t = 0.0, s_p = 0.0, s_w = 0.0;
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r0 = (blockIdx.y * 4 + rt) * FT_R;
+        if (r0 >= rows) break;
+        for (int i = 0; i < 16; ++i) {
+            const int r = w + 4 * i, row = r0 + r;
+            const bool in = cin && row < rows;
+            float4 v4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g4 = v4;
+            if (in) {
+                v4 = *reinterpret_cast<const float4*>(x + (long)row * n + col);
+                g4 = *reinterpret_cast<const float4*>(dfm + (long)row * n + col);
+            }
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            uint16_t h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = (v[k] > th[k] && v[k] > 0.0f) ? v[k] : 0.0f;
+                const float wv = f * nrm[k] * c;
+                const float t = use_tanh ? tanhf(wv) : wv;
+                const float dt = use_tanh ? (1.0f - t * t) : 1.0f;
+                float dp = 0.0f;
+                if (in) {
+                    s_t += (double)t; s_w += (double)wv; s_p += (double)(v[k] < 0.0f ? -v[k] : 0.0f);
+                    const float df = gg[k] + lamB * dt * c * nrm[k];
+                    dp = (v[k] < 0.0f ? 0.0f : df) - (v[k] < 0.0f ? coefBL : 0.0f);
+                    a_th[k] += thc[k] * rect_window(v[k], th[k], bw) * df;
+                    a_dn[k] += lamB * dt * c * f;
+                    a_db[k] += dp;
+                }
+                h[k] = f32_to_bf16(dp);
+            }
+            ft_store_row(tile, r, tx, h);
+        }
+        __syncthreads();
+        ft_write_transposed(tile, dpreT, c0, r0, rows, n);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][w][4 * tx + k] = a_th[k]; red[1][w][4 * tx + k] = a_dn[k]; red[2][w][4 * tx + k] = a_db[k]; }
+    __syncthreads();
+    {
+        const int j = threadIdx.x;
+        if (c0 + j < n) {
+            const long stride = (long)gridDim.y * n;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                part[q * stride + (long)blockIdx.y * n + c0 + j] = ((red[q][0][j] + red[q][1][j]) + red[q][2][j]) + red[q][3][j];
+        }
+    }
+    const long b = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    double s;
+    s = block_sum_d(s_t, sh); if (threadIdx.x == 0) part_s[b * 3 + 0] = s;
+    s = block_sum_d(s_p, sh); if (threadIdx.x == 0) part_s[b * 3 + 1] = s;
+    s = block_sum_d(s_w, sh); if (threadIdx.x == 0) part_s[b * 3 + 2] = s;
+}
+
 // out[r*ld_out + j] = bias[j] + sum_s slabs[s*slab_stride + r*n + j]   (split-K partial results of the dense
 // cross-layer decoder: one [rows][n] slab per source layer, summed in source-layer order)
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, long total, int n, long ld_out,
@@ -465,6 +606,36 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
         hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pth, ch, n, dtheta, 0);
         hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pdn, ch, n, dnorm, 0);
     }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_jumprelu_fwd_bf16(const float* x, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT, uint8_t* fired,
+                          void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta))) return CLT_ERR_ALIGN;
+    if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel, dim3((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R), dim3(256), 0, as_stream(st),
+                       x, theta, rows, n, feat, featT, fired);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n) {
+    const size_t gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C;
+    return align_up(3 * gy * (size_t)n * sizeof(float), 16) + gx * gy * 3 * sizeof(double);
+}
+int clt_jumprelu_loss_bwd_bf16(const float* x, const float* theta, const float* sq, const float* dfm, float bw, float lamB, float c,
+                               int use_tanh, float coefBL, uint16_t* dpreT, float* dbias, float* dtheta, float* dnorm,
+                               double* sums, int rows, int n, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0 || !x || !theta || !sq || !dfm || !dpreT || !dbias || !dtheta || !dnorm || !sums) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(theta) || !aligned16(sq) || !aligned16(dfm) || !aligned16(dpreT)) return CLT_ERR_ALIGN;
+    if (!ws || wsb < clt_jumprelu_loss_bf16_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    const int gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C, gc = (n + TPB - 1) / TPB;
+    float* part = (float*)ws;
+    double* ps = (double*)((char*)ws + align_up((size_t)3 * gy * n * sizeof(float), 16));
+    hipLaunchKernelGGL(jumprelu_loss_bf16_kernel, dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, dfm, bw, lamB, c, use_tanh,
+                       coefBL, dpreT, part, ps, rows, n);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * gy, 3, sums);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)part, gy, n, dtheta, 0);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)gy * n), gy, n, dnorm, 0);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)2 * gy * n), gy, n, dbias, 0);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_column_any_positive_f32(const float* f, int rows, int n, uint8_t* fired, void* st) {

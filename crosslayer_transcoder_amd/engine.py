@@ -86,6 +86,9 @@ class StepOutput(dict):
 FUSE_ENCODER_SELECT = True
 #: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
 SELECT_MARGIN = 0.9
+#: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
+#: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
+FUSE_DENSE_JUMPRELU = True
 
 
 def _encoder_operand(enc):
@@ -144,9 +147,10 @@ class _Decoder:
     def _reduce(self, r):
         return r if self.shard is None else self.shard.all_reduce_sum(r)
 
-    def fwd(self, feat):
+    def fwd(self, feat, feat_op=None):
+        """feat: fp32 [B, L, F]; feat_op: its bf16 copy when the caller already has one (then feat may be None)."""
         if self.bf16:
-            fo = ops.cast_bf16(feat)
+            fo = feat_op if feat_op is not None else ops.cast_bf16(feat)
             r = ops.clt_decoder_fwd_t(fo, self.WT, self._bias()) if self.clt else ops.plt_decoder_fwd_t(fo, self.WT[0], self._bias())
         else:
             r = ops.clt_decoder_fwd(feat, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(feat, self.Wop[0], self._bias())
@@ -156,22 +160,23 @@ class _Decoder:
         go = _op(g)
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
 
-    def wgrad(self, feat, g, grads: Dict[str, torch.Tensor]):
-        """grads[name] (+)= feat^T @ g; accumulates when the entry already exists."""
-        Bn, L, F = feat.shape
-        d = g.shape[2]
+    def wgrad(self, feat, g, grads: Dict[str, torch.Tensor], featT=None):
+        """grads[name] (+)= feat^T @ g; accumulates when the entry already exists.  featT: bf16 [L, F, B] when the
+        caller already has the transposed operand (then feat may be None)."""
+        Bn, d = g.shape[0], g.shape[2]
+        L, F = self.L, self.dec.d_features
         if self.bf16:
-            fT = ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
+            fT = featT if featT is not None else ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
             gT = ops.transpose_cast_2d(g).view(L, d, Bn)             # [L, d, B]
             if self.clt:
                 for l in range(L):
                     k = f"decoder.W_{l}"
                     acc = k in grads
-                    out = grads[k] if acc else torch.empty(l + 1, F, d, dtype=torch.float32, device=feat.device)
+                    out = grads[k] if acc else torch.empty(l + 1, F, d, dtype=torch.float32, device=g.device)
                     grads[k] = ops.wgrad_t(fT, gT[l], out, l + 1, F * Bn, 0, acc)
             else:
                 acc = "decoder.W" in grads
-                out = grads["decoder.W"] if acc else torch.empty(L, F, d, dtype=torch.float32, device=feat.device)
+                out = grads["decoder.W"] if acc else torch.empty(L, F, d, dtype=torch.float32, device=g.device)
                 grads["decoder.W"] = ops.wgrad_t(fT, gT, out, L, F * Bn, d * Bn, acc)
             return
         if self.clt:
@@ -284,7 +289,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if shard is not None and shard.world == 1 and not shard.keep_single:
         shard = None
     theta = None
-    feat = S = pre = None
+    feat = S = pre = fused_ops = dpreT = None
     batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
     if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
             and getattr(nl, "_kth", None) is not None and d % 64 == 0 and F % 4 == 0):
@@ -301,6 +306,10 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         S = _select_lists(nl, pre, shard=shard)
         if batch_mode:
             nl._kth = getattr(S, "kth", None)
+    elif (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
+          and (L * F) % 4 == 0):
+        theta = nl.theta if isinstance(nl, JumpReLU) else None
+        fused_ops = ops.jumprelu_fwd_bf16(pre, theta)            # (feat bf16, feat^T bf16, fired)
     elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
@@ -319,6 +328,9 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if sparse:
         r = D.sparse_fwd(S)
         fired = S.fired
+    elif fused_ops is not None:
+        r = D.fwd(None, feat_op=fused_ops[0])
+        fired = fused_ops[2]
     else:
         r = D.fwd(feat)
         fired = ops.column_any_positive(feat)
@@ -335,6 +347,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         out.lazy = {"pre_actvs": lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)}
     if feat is not None:
         out["features"] = feat
+    elif fused_ops is not None:
+        out.lazy = {"features": (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))}
 
     if sparse:
         S2 = g_aux = None
@@ -379,11 +393,15 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         bw = nl._bandwidth if theta is not None else 1.0
         sq = D.sqnorms()
         dfeat = D.dgrad(g)
-        sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
-                                                    mod.pre_actv_loss / (Bn * L))
+        if fused_ops is not None:
+            sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
+                                                                  mod.pre_actv_loss / (Bn * L))
+        else:
+            sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
+                                                        mod.pre_actv_loss / (Bn * L))
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
-        D.wgrad(feat, g, grads)
+        D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
         D.add_norm_grads(dn, sq, grads)
         grads["decoder.b"] = ops.column_sum(g)
         if theta is not None:
@@ -420,11 +438,12 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
 
     if bf16:       # dWt[l] [F, d] = dpre[:, l]^T @ xs[:, l], contraction over tokens: both operands token-minor
         dWt = torch.empty(L, F, d, dtype=torch.float32, device=pre.device)
-        ops.wgrad_t(ops.transpose_cast_2d(dpre).view(L, F, Bn), ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt, L, F * Bn, d * Bn)
+        dT = dpreT if dpreT is not None else ops.transpose_cast_2d(dpre).view(L, F, Bn)
+        ops.wgrad_t(dT, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt, L, F * Bn, d * Bn)
         grads["encoder.W"] = dWt.permute(0, 2, 1)
     else:
         grads["encoder.W"] = ops.encoder_wgrad(xo, dpre).permute(0, 2, 1)
-    grads["encoder.b"] = ops.column_sum(dpre)
+    grads["encoder.b"] = db if dpreT is not None else ops.column_sum(dpre)
     terms["loss"] = loss
     out["loss"] = loss
     return out

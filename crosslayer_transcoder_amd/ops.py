@@ -418,6 +418,40 @@ def jumprelu_loss_bwd(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_
     return sums, dpre, dth, dn
 
 
+def jumprelu_fwd_bf16(x, theta=None):
+    """Dense bf16 regime: JumpReLU (theta=None: ReLU) straight to the GEMM operands.  x: fp32 [B, L, F].
+    Returns (feat bf16 [B, L, F], featT bf16 [L, F, B], fired uint8 [L, F])."""
+    _chk(x)
+    Bn, L, F = x.shape
+    if theta is not None:
+        _chk(theta)
+        assert theta.numel() == L * F
+    feat = torch.empty(Bn, L, F, dtype=torch.bfloat16, device=x.device)
+    featT = torch.empty(L, F, Bn, dtype=torch.bfloat16, device=x.device)
+    fired = torch.empty(L, F, dtype=torch.uint8, device=x.device)
+    call("clt_jumprelu_fwd_bf16", x.data_ptr(), theta.data_ptr() if theta is not None else None, Bn, L * F, feat.data_ptr(),
+         featT.data_ptr(), fired.data_ptr(), _stream())
+    return feat, featT, fired
+
+
+def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_tanh, coef_over_BL):
+    """jumprelu_loss_bwd for the dense bf16 regime: returns (sums fp64 [3], dpreT bf16 [L, F, B], dbias fp32 [L, F],
+    dtheta, dnorm) — no fp32 dpre tensor."""
+    _chk(pre); _chk(theta); _chk(sq); _chk(dfeat_main)
+    Bn, L, F = pre.shape
+    n = L * F
+    sums = torch.empty(3, dtype=torch.float64, device=pre.device)
+    dpreT = torch.empty(L, F, Bn, dtype=torch.bfloat16, device=pre.device)
+    db = torch.empty(L, F, dtype=torch.float32, device=pre.device)
+    dth = torch.empty_like(theta)
+    dn = torch.empty(n, dtype=torch.float32, device=pre.device)
+    ws = workspace(lib.clt_jumprelu_loss_bf16_workspace_bytes(Bn, n), pre.device)
+    call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), theta.data_ptr(), sq.data_ptr(), dfeat_main.data_ptr(), float(bandwidth),
+         float(lam_over_B), float(c), int(use_tanh), float(coef_over_BL), dpreT.data_ptr(), db.data_ptr(), dth.data_ptr(),
+         dn.data_ptr(), sums.data_ptr(), Bn, n, ws.data_ptr(), ws.numel(), _stream())
+    return sums, dpreT, db, dth, dn
+
+
 def rowscale_add(W, dnorm, sq, dW, off=0):
     """dW[row] += dnorm[off+row]/sqrt(sq[off+row]) * W[row]."""
     d = W.shape[-1]

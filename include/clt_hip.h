@@ -146,6 +146,20 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
                               float bandwidth, float lam_over_B, float c, int use_tanh, float coef_over_BL,
                               float* dpre, float* dtheta, float* dnorm, double* sums, int rows, int n,
                               void* workspace, size_t ws_bytes, void* stream);
+/* Dense bf16 regime, fused tile passes (jumprelu.py:31-48 + the operand casts/transposes that the reference's autocast
+ * and autograd do implicitly).  x: [rows][n] fp32 (rows = tokens, n = layers*features); rows % 8 == 0, n % 4 == 0,
+ * 16-byte aligned pointers (else CLT_ERR_ALIGN: use the unfused entry points).
+ *   clt_jumprelu_fwd_bf16:  feat[r][j] = bf16(jumprelu(x, theta)) ; featT[j][r] = the same, transposed ;
+ *                           fired[j] = any_r feat > 0 (K12).  theta may be NULL (ReLU).  No fp32 feature tensor.
+ *   clt_jumprelu_loss_bwd_bf16: the math of clt_jumprelu_loss_bwd_f32, but d(loss)/d(pre) leaves only as the transposed
+ *                           bf16 GEMM operand dpreT[j][r] plus its fp32 column sums dbias[j] (encoder bias gradient). */
+int clt_jumprelu_fwd_bf16(const float* x, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT, uint8_t* fired,
+                          void* stream);
+size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n);
+int clt_jumprelu_loss_bwd_bf16(const float* x, const float* theta, const float* sq, const float* dfeat_main, float bandwidth,
+                               float lam_over_B, float c, int use_tanh, float coef_over_BL, uint16_t* dpreT, float* dbias,
+                               float* dtheta, float* dnorm, double* sums, int rows, int n, void* workspace, size_t ws_bytes,
+                               void* stream);
 /* dW[row][:] += (dnorm[row]/sqrt(sq[row])) * W[row][:]   (gradient through dec_norms). */
 int clt_rowscale_add_f32(const float* W, const float* dnorm, const float* sq, float* dW, int rows, int d,
                          void* stream);

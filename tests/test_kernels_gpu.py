@@ -492,3 +492,31 @@ def test_gemm_nt_fast_path(ops, Bn, L, d, F):
     eye = torch.eye(n).to(bf)
     out = ops.encoder_fwd(eye.reshape(n, 1, n).to(DEV), Bm.reshape(1, n, n).to(DEV), None)
     assert torch.equal(out.cpu().reshape(n, n), Bm.float().T)
+
+
+@pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4)])
+def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
+    """clt_jumprelu_fwd_bf16 / clt_jumprelu_loss_bwd_bf16 against the separate fp32 passes + casts (ragged tiles:
+    rows not a multiple of 64, columns not a multiple of 256)."""
+    g = torch.Generator().manual_seed(rows + F)
+    x = torch.randn(rows, L, F, generator=g).cuda()
+    theta = (torch.rand(1, L, F, generator=g) * 0.5).cuda()
+    feat = ops.jumprelu_fwd(x, theta)
+    fb, fT, fired = ops.jumprelu_fwd_bf16(x, theta)
+    assert torch.equal(fb, ops.cast_bf16(feat))
+    assert torch.equal(fT, ops.transpose_cast_2d(feat).view(L, F, rows))
+    assert torch.equal(fired, ops.column_any_positive(feat))
+    fb0, fT0, fired0 = ops.jumprelu_fwd_bf16(x, None)
+    relu = ops.relu_fwd(x)
+    assert torch.equal(fb0, ops.cast_bf16(relu)) and torch.equal(fT0, ops.transpose_cast_2d(relu).view(L, F, rows))
+    assert torch.equal(fired0, ops.column_any_positive(relu))
+    sq = (torch.rand(L * F, generator=g) + 0.1).cuda()
+    df = torch.randn(rows, L, F, generator=g).cuda()
+    for tanh in (True, False):
+        args = (x, theta, sq, df, 0.3, 0.01, 1.5, tanh, 1e-3)
+        s1, dpre, dth1, dn1 = ops.jumprelu_loss_bwd(*args)
+        s2, dT, db, dth2, dn2 = ops.jumprelu_loss_bwd_bf16(*args)
+        assert torch.equal(dT, ops.transpose_cast_2d(dpre).view(L, F, rows))
+        for a, b, nm in ((s2, s1, "sums"), (dth2, dth1, "dtheta"), (dn2, dn1, "dnorm"), (db, ops.column_sum(dpre), "dbias")):
+            a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max())), nm

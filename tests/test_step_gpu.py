@@ -187,6 +187,26 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
         gg = out["grads"][k].reshape(gref.shape).cpu()
         rel = (gg - gref).norm() / (gref.norm() + 1e-12)
         assert rel < 2e-2, f"{dec_kind}/{nl_kind} bf16 grad {k}: rel l2 err {rel:.3g}"
+    if loss_kind == "jumprelu":
+        # the fused tile passes (bf16 operands written directly) against the separate fp32 passes + casts: the GEMM
+        # operands are bit-identical, only the column-sum / loss-sum reduction trees differ
+        from crosslayer_transcoder_amd import engine
+        assert "features" not in dict.keys(out), "the fused dense path should not materialise fp32 features"
+        mod2 = build_module(case)
+        mod2.global_step = 5
+        engine.FUSE_DENSE_JUMPRELU = False
+        try:
+            with precision("bf16-mixed"):
+                out2 = mod2.compute_step(batch.cuda(), 0, sparse=False)
+        finally:
+            engine.FUSE_DENSE_JUMPRELU = True
+        assert "features" in dict.keys(out2)
+        assert torch.equal(out["features"], out2["features"])
+        assert torch.equal(out["recons_norm"], out2["recons_norm"])
+        assert torch.equal(out["dead"], out2["dead"])
+        assert_close(out["loss"], out2["loss"], 1e-6, 0, "fused vs unfused loss")
+        for k, g2 in out2["grads"].items():
+            assert_close(out["grads"][k], g2, 1e-5, 1e-6 * float(g2.abs().max()), f"fused vs unfused grad {k}")
 
 
 @pytest.mark.parametrize("nl_kind", ["batchtopk", "perlayerbatchtopk"])
