@@ -53,7 +53,7 @@ def build(args, device, rank=0, world=1):
             mod.global_step = 50_000               # global_step / max_steps = 0.5
         elif args.aux:
             mod = TopKCrossLayerTranscoderModule(model=model, topk_aux=PerLayerTopK(k=512), learning_rate=1e-4,
-                                                 tokens_till_dead=args.batch * 3)
+                                                 tokens_till_dead=args.batch * args.dead_steps)
         else:
             mod = CrossLayerTranscoderModule(model=model, learning_rate=1e-4)
     mod.trainer.max_steps = 100_000
@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--d-acts", type=int, default=768)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--aux", action="store_true", help="TopK module with the k_aux=512 dead-feature loss")
+    ap.add_argument("--dead-steps", type=int, default=1,
+                    help="--aux: a feature is dead after this many steps without firing (1 -> about 14 %% dead on the synthetic "
+                         "data, the ~10 %% of BASELINE.md config 3; 3 -> 0.3 %%)")
     ap.add_argument("--nonlinearity", default="batchtopk", choices=["batchtopk", "topk", "relu", "jumprelu"])
     ap.add_argument("--decoder", default="clt", choices=["clt", "plt"])
     ap.add_argument("--precision", default="bf16-mixed")

@@ -68,7 +68,10 @@ SIGNATURES = {
                                      P, P, SZ, P]),
     "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
-                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P]),
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P]),
+    "clt_compact_columns": (I, [P, I, I, I, P, P, P, P]),
+    "clt_gather_cols_f32": (I, [P, P, I, I, I, I, F32, P, P]),
+    "clt_gather_rows_f32": (I, [P, P, I, I, I, I, P, P]),
     "clt_sparse_reduce_dots_f32": (I, [P, L, P, I, I, I, P, P]),
     "clt_sparse_scatter_dense_f32": (I, [P, P, P, I, I, P, P]),
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P]),

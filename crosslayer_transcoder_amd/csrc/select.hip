@@ -6,6 +6,7 @@
 // and LDS histograms; everything > T is selected, and of the entries == T the lowest-index ones fill
 // the remaining slots (canonical tie rule of the build).  Entries whose value is <= 0
 // contribute relu(v) = 0, so ties at T <= 0 never change the output and are not ranked.
+#include <stdlib.h>
 #include "select_common.h"
 
 namespace {
@@ -80,6 +81,212 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
                 int pos = 0;
                 for (int q = 0; q < n; ++q) pos += cidx[q] < me;
                 idx_out[row * k + pos] = me; val_out[row * k + pos] = cval[e];
+            } else { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mode 0, register-resident rows (F <= 32768, 16-byte aligned rows): one 1024-thread block per row reads the row ONCE
+// (coalesced 16-byte loads) and keeps the order-preserving keys in registers.  The exact k-th largest key is found by a
+// binary search on the key bits, two bits per step (three thresholds counted at once with wave ballots, one workgroup
+// barrier per step) — first over the 1024 per-thread maxima, whose k-th largest is a lower bound of the row's k-th
+// largest (k <= 1024), then over the few candidates >= that bound (compacted into LDS).  No LDS atomics on the data,
+// so no contention on the handful of exponent bins that nearly all pre-activations share.
+// ------------------------------------------------------------------------------------------------
+constexpr int RT = 1024, RW = RT / 64, RCAP = 4096;
+
+// m-th largest of the 64 values one wave holds (one per lane): binary search on the key bits, two bits per step, counted
+// with ballots — scalar work only, no LDS, no barrier.
+__device__ __forceinline__ uint32_t wave_kth(uint32_t v, uint32_t m) {
+    uint32_t t = 0;
+    for (int b = 30; b >= 0; b -= 2) {
+        const uint32_t c1 = (uint32_t)__popcll(__ballot(v >= (t | (1u << b))));
+        const uint32_t c2 = (uint32_t)__popcll(__ballot(v >= (t | (2u << b))));
+        const uint32_t c3 = (uint32_t)__popcll(__ballot(v >= (t | (3u << b))));
+        if (c3 >= m) t |= 3u << b;
+        else if (c2 >= m) t |= 2u << b;
+        else if (c1 >= m) t |= 1u << b;
+    }
+    return t;
+}
+
+template <int NPT>
+__global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
+                                                           int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                           const uint8_t* __restrict__ col_mask, int L,
+                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt) {
+    __shared__ uint2 red[2][RW];
+    __shared__ uint32_t ckey[RCAP];
+    __shared__ uint32_t wtot[RW];
+    __shared__ uint32_t wlb[RW];
+    __shared__ uint32_t step_cnt[16][4];                   // block-wide search: per step the counts of 3 thresholds
+    __shared__ uint32_t cursor, Tsh;
+    __shared__ int32_t oidx[MAXK_COMPACT];
+    __shared__ float oval[MAXK_COMPACT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long row = blockIdx.x;
+    const float* xr = x + row * F;
+    const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+    int parity = 0;
+    if (tid < 64) step_cnt[tid >> 2][tid & 3] = 0;
+    if (tid == 0) cursor = 0;
+    // element e of this thread has index ((e / 4) * RT + tid) * 4 + e % 4; keys of positions >= F are 0 (below every real key)
+    uint32_t key[NPT];
+    uint32_t tmax = 0;
+#pragma unroll
+    for (int j = 0; j < NPT / 4; ++j) {
+        const int i0 = (j * RT + tid) * 4;
+        const bool in = i0 < F;
+        const int ic = in ? i0 : 0;                            // branch-free: out-of-range groups re-read the row start
+        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
+        float a[4] = {v.x, v.y, v.z, v.w};
+        if (mk) {
+            const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
+            a[0] = m4.x ? a[0] : -INFINITY; a[1] = m4.y ? a[1] : -INFINITY; a[2] = m4.z ? a[2] : -INFINITY; a[3] = m4.w ? a[3] : -INFINITY;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t kk = in ? f32_key(a[c]) : 0u; key[j * 4 + c] = kk; tmax = max(tmax, kk); }
+    }
+    // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
+    // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
+    uint32_t LB = 0;
+    if (k <= RT) {
+        const uint32_t mth = wave_kth(tmax, (uint32_t)(k + RW - 1) / RW);
+        if (lane == 0) wlb[w] = mth;
+    }
+    // candidates >= LB, compacted into LDS
+    __syncthreads();
+    if (k <= RT) {
+        LB = wlb[0];
+#pragma unroll
+        for (int i = 1; i < RW; ++i) LB = min(LB, wlb[i]);
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) cnt += key[e] >= LB ? 1u : 0u;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) { const uint32_t s = wtot[i]; if (i < w) base += s; total += s; }
+    uint32_t T;
+    if (total <= (uint32_t)RCAP) {
+        uint32_t pos = base + inc - cnt;
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) if (key[e] >= LB) ckey[pos++] = key[e];
+        __syncthreads();
+        if (total <= 64u) {                                 // the usual case for k << F: one wave finishes the search alone
+            if (w == 0) {
+                const uint32_t t = wave_kth((uint32_t)lane < total ? ckey[lane] : 0u, (uint32_t)k);
+                if (lane == 0) Tsh = t;
+            }
+        } else {                                            // all waves count, one LDS atomic per wave, threshold and step
+            uint32_t ck[RCAP / RT];
+#pragma unroll
+            for (int q = 0; q < RCAP / RT; ++q) { const uint32_t j = tid + q * RT; ck[q] = j < total ? ckey[j] : 0u; }
+            uint32_t t = 0;
+            for (int b = 30, st = 0; b >= 0; b -= 2, ++st) {
+                uint32_t c[3] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < RCAP / RT; ++q) {
+                    c[0] += (uint32_t)__popcll(__ballot(ck[q] >= (t | (1u << b)))); c[1] += (uint32_t)__popcll(__ballot(ck[q] >= (t | (2u << b))));
+                    c[2] += (uint32_t)__popcll(__ballot(ck[q] >= (t | (3u << b))));
+                }
+                if (lane < 3) { const uint32_t mine = lane == 0 ? c[0] : (lane == 1 ? c[1] : c[2]); if (mine) atomicAdd(&step_cnt[st][lane], mine); }
+                __syncthreads();
+                const uint32_t s1 = step_cnt[st][0], s2 = step_cnt[st][1], s3 = step_cnt[st][2];
+                if (s3 >= (uint32_t)k) t |= 3u << b;
+                else if (s2 >= (uint32_t)k) t |= 2u << b;
+                else if (s1 >= (uint32_t)k) t |= 1u << b;
+            }
+            if (tid == 0) Tsh = t;
+        }
+        __syncthreads();
+        T = Tsh;
+    } else {                                               // (k > 1024, or a row of mostly equal values): search all the keys,
+        T = 0;                                             // one bit and one threshold per step
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t cand = T | (1u << b);
+            uint32_t c = 0;
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) c += key[e] >= cand ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0) red[parity][w] = make_uint2(c, 0u);
+            __syncthreads();
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) sum += red[parity][i].x;
+            parity ^= 1;
+            if (sum >= (uint32_t)k) T = cand;
+        }
+    }
+    // counts above / at T
+    uint32_t cgt = 0, ceq = 0;
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) { cgt += key[e] > T ? 1u : 0u; ceq += key[e] == T ? 1u : 0u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cgt += __shfl_xor(cgt, o, 64); ceq += __shfl_xor(ceq, o, 64); }
+    if (lane == 0) red[parity][w] = make_uint2(cgt, ceq);
+    __syncthreads();
+    uint32_t ngt = 0, neq = 0;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) { const uint2 r = red[parity][i]; ngt += r.x; neq += r.y; }
+    parity ^= 1;
+    const uint32_t krem = (uint32_t)k - ngt;
+    const bool rank_ties = (neq != krem) && (key_f32(T) > 0.0f);
+    uint32_t running = 0;                                   // ties before this group of 4 * RT indices
+    float* fr = feat ? feat + row * F : nullptr;
+#pragma unroll
+    for (int j = 0; j < NPT / 4; ++j) {
+        const int i0 = (j * RT + tid) * 4;
+        uint32_t before = 0;                                // ties with a lower index inside this group
+        if (rank_ties) {                                    // (block-uniform branch) ordered scan: thread order, then c
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += key[j * 4 + c] == T ? 1u : 0u;
+            uint32_t sc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+            if (lane == 63) red[parity][w] = make_uint2(sc, 0u);
+            __syncthreads();
+            uint32_t pb = 0, pt = 0;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) { const uint32_t s2 = red[parity][i].x; if (i < w) pb += s2; pt += s2; }
+            parity ^= 1;
+            before = running + pb + sc - mine;
+            running += pt;
+        }
+        float o4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t kk = key[j * 4 + c];
+            bool sel = kk > T;
+            if (kk == T) { sel = rank_ties ? before < krem : true; ++before; }
+            const float v = key_f32(kk);
+            o4[c] = (sel && v > 0.0f && i0 + c < F) ? v : 0.0f;
+            if (idx_out && o4[c] > 0.0f) {
+                const uint32_t sl = atomicAdd(&cursor, 1u);
+                oidx[sl] = i0 + c; oval[sl] = o4[c];
+                if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + i0 + c], 1u);
+            }
+        }
+        if (fr && i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    if (idx_out) {                          // order the <= k positive entries by feature index (rank sort)
+        __syncthreads();
+        const int n = (int)cursor;
+        if (row_cnt && tid == 0) row_cnt[row] = n;
+        for (int e = tid; e < k; e += RT) {
+            if (e < n) {
+                const int me = oidx[e];
+                int pos = 0;
+                for (int q = 0; q < n; ++q) pos += oidx[q] < me;
+                idx_out[row * k + pos] = me; val_out[row * k + pos] = oval[e];
             } else { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
         }
     }
@@ -209,8 +416,16 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         if (row_cnt && hipMemsetAsync(row_cnt, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         return CLT_OK;
     }
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt,
-                       col_cnt);
+    const bool reg_ok = F % 4 == 0 && F <= 32 * RT && aligned16(x) && (!feat || aligned16(feat)) &&
+                        (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !getenv("CLT_TOPK_ROWS_V1");
+    if (reg_ok) {
+#define TKR(NPT_) hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(rows), dim3(RT), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt)
+        const int per = (F + RT - 1) / RT;
+        if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 16) TKR(16); else TKR(32);
+#undef TKR
+    } else
+        hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt,
+                           col_cnt);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 

@@ -114,6 +114,9 @@ struct RowPassArgs {
     float* colsum_out;           // optional: colsum_out[col] = sum coef (encoder bias gradient)
     float lr, omb1, b2, omb2, eps, wd, step_size, isb2; int adamw;
     int src_bf16;                // src / src2 hold bf16 (uint16_t) elements instead of fp32: halves the gather traffic
+    // optional dense contribution for a subset of the rows (the compacted TopK-aux pass, compact.hip):
+    //   grad[r,:] += extra[extra_map[col0 + r], :] ; colsum_out[col] += extra_colsum[extra_map[col]]   (map < 0: none)
+    const float* extra; const int32_t* extra_map; const float* extra_colsum;
 };
 
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
@@ -206,6 +209,21 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
                 if (lane == 0 && wave == (CW == 1 ? wave : 0))
                     dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p] = dot;
             }
+        }
+    }
+    if (a.extra) {
+        const int mr = a.extra_map[col];
+        if (mr >= 0) {
+            const float* er = a.extra + (long)mr * a.d;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int o = cb + (t * 64 + lane) * W;
+                if (o < a.d) {
+                    if (VEC) { const float4 x = *reinterpret_cast<const float4*>(er + o); g[t][0] += x.x; g[t][1 % W] += x.y; g[t][2 % W] += x.z; g[t][3 % W] += x.w; }
+                    else g[t][0] += er[o];
+                }
+            }
+            if (a.extra_colsum) csum += a.extra_colsum[mr];
         }
     }
     if (a.colsum_out && lane == 0 && (CW == 1 || wave == 0)) a.colsum_out[col] = csum;
@@ -370,12 +388,14 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             float* colsum_out,
                             double lr,
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
-                            void* stp) {
+                            const float* extra, const int32_t* extra_map, const float* extra_colsum, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
     RowPassArgs a;
     a.W = W; a.m = m; a.v = v; a.shadow = shadow; a.grad_out = grad_out; a.rows = rows; a.d = d; a.F = F; a.col0 = col0;
     a.src_bf16 = src_bf16;
+    if (extra && !extra_map) return CLT_ERR_SHAPE;
+    a.extra = extra; a.extra_map = extra_map; a.extra_colsum = extra ? extra_colsum : nullptr;
     a.src_layer = src_layer; a.L = L; a.col_start = col_start; a.tok = tok; a.coef = coef; a.src = src;
     a.col_start2 = col_start2; a.tok2 = tok2; a.coef2 = coef2; a.src2 = src2; a.dot_out = dot_out; a.dot_out2 = dot_out2; a.dot_stride = dot_stride; a.dot_stride2 = dot_stride2;
     a.dot_slot_base = dot_slot; a.colsum_out = colsum_out;
@@ -385,7 +405,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     a.wd = (float)weight_decay; a.step_size = (float)(lr / bc1); a.isb2 = (float)(1.0 / sqrt(bc2)); a.adamw = adamw;
     const bool vec = d % 4 == 0 && aligned16(W) && (src_bf16 ? (reinterpret_cast<uintptr_t>(src) & 7) == 0 : aligned16(src)) && (!m || aligned16(m)) && (!v || aligned16(v)) &&
                      (!grad_out || aligned16(grad_out)) && (!src2 || (src_bf16 ? (reinterpret_cast<uintptr_t>(src2) & 7) == 0 : aligned16(src2))) &&
-                     (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
+                     (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0) && (!extra || aligned16(extra));
     hipStream_t st = as_stream(stp);
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);   // 64-lane iterations a whole row needs
     const dim3 g4((rows + 3) / 4), g1(rows);

@@ -86,6 +86,10 @@ class StepOutput(dict):
 FUSE_ENCODER_SELECT = True
 #: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
 SELECT_MARGIN = 0.9
+#: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
+#: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
+COMPACT_AUX = True
+COMPACT_AUX_MAX_SHARE = 0.5
 #: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
 FUSE_DENSE_JUMPRELU = True
@@ -106,19 +110,30 @@ def _encoder_operand(enc):
     return sh
 
 
+class _CompactDecoder:
+    """Stand-in for a decoder module restricted to n_pad gathered feature rows per source layer (the compacted
+    TopK-aux pass): what _Decoder needs of a decoder, on the gathered weights."""
+
+    def __init__(self, dec, Wc, n_pad):
+        self.n_layers, self.d_acts, self.d_features, self.b, self._W = dec.n_layers, dec.d_acts, n_pad, dec.b, Wc
+
+    def weights(self):
+        return self._W
+
+
 class _Decoder:
     """Decoder passes for either decoder class.  Dense passes take fp32 tensors and form their GEMM operands in
     the active precision: fp32 -> the exact-fp32 MFMA kernel on the natural layouts; bf16 -> every contraction in
     the k-contiguous "NT" form of the glds MFMA kernel, with transposed bf16 copies where the natural layout has
     the contraction index outermost (decoder forward: weights^T; weight gradients: features^T and g^T)."""
 
-    def __init__(self, dec, shard=None, shadow=False):
+    def __init__(self, dec, shard=None, shadow=False, clt=None):
         self.dec = dec
         self.shard = shard
         #: sparse regime, bf16 mode, Adam fused into the row pass: the gather forward reads bf16 shadow copies of the
         #: decoder matrices that the same row pass keeps current (half the gathered bytes)
         self.shadow = shadow
-        self.clt = isinstance(dec, CrosslayerDecoder)
+        self.clt = isinstance(dec, CrosslayerDecoder) if clt is None else clt
         self.L = dec.n_layers
         self.W32 = dec.weights()
         self.bf16 = get_precision() == "bf16"
@@ -223,9 +238,10 @@ class _Decoder:
         return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt,
                                                    w_bf16=self.shadow))
 
-    def sparse_bwd(self, S, g, S2, g2, grads, fused):
+    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
-        Returns (dval [S.cap], dval2 [S2.cap] or None)."""
+        Returns (dval [S.cap], dval2 [S2.cap] or None).  extra = ({name: compact dW}, map): dense gradient of the
+        compacted aux pass, added to the mapped rows."""
         dev = g.device
         slots = self.L if self.clt else 1
         dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
@@ -236,6 +252,8 @@ class _Decoder:
         second = (S2, S2.csc_val, g2) if S2 is not None else None
         for l, (name, w) in enumerate(zip(self.names(), self.W32)):
             kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
+            if extra is not None:
+                kw["extra"] = (extra[0][name].view(-1, w.shape[-1]), extra[1], None)
             if fused is not None:
                 kw.update(fused.begin_fused(w))
                 if self.shadow:
@@ -351,11 +369,22 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         out.lazy = {"features": (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))}
 
     if sparse:
-        S2 = g_aux = None
+        S2 = g_aux = cx = None
         if kind == "topk":
             aux = mod.topk_aux
-            S2 = _select_lists(aux, pre, dead, shard)
-            aux_r = D.sparse_fwd(S2)
+            if COMPACT_AUX and shard is None and isinstance(aux, PerLayerTopK) and aux.k > 0:
+                cx = ops.compact_columns(dead)                      # one host read: the per-layer dead counts
+                if cx is not None and cx[0] > COMPACT_AUX_MAX_SHARE * F:
+                    cx = None
+            if cx is not None:
+                # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
+                n_pad, cidx, cmap = cx
+                feat_c = ops.topk_rows(ops.gather_cols(pre, cidx, float("-inf")), min(aux.k, n_pad))
+                Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), None, clt=D.clt)
+                aux_r = Dc.fwd(feat_c)
+            else:
+                S2 = _select_lists(aux, pre, dead, shard)
+                aux_r = D.sparse_fwd(S2)
             aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
             terms["aux"] = (aux_sum[0] / N).float()
             loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
@@ -363,13 +392,26 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         else:
             loss = terms["mse"]
         grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
-        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux, grads, optimizer)
+        xsrc = xs16 if bf16 else xs32
+        extra_dec = extra_enc = None
+        if cx is not None:
+            gc: Dict[str, torch.Tensor] = {}
+            Dc.wgrad(feat_c, g_aux, gc)
+            dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
+            if bf16:
+                dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=xs32.device)
+                ops.wgrad_t(ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn), ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L,
+                            n_pad * Bn, d * Bn)
+            else:
+                dWt_c = ops.encoder_wgrad(xs32, dpre_c)
+            extra_dec = (gc, cmap)
+            extra_enc = (dWt_c.view(-1, d), cmap, ops.column_sum(dpre_c).view(-1))
+        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec)
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
         db = torch.empty(L, F, dtype=torch.float32, device=xs32.device)
         Wt = enc.Wt
-        xsrc = xs16 if bf16 else xs32
-        kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None)
+        kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None, extra=extra_enc)
         if optimizer is not None:
             kw.update(optimizer.begin_fused(enc.W, storage=Wt))
             if bf16:

@@ -737,12 +737,17 @@ def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.
 
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
-                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None):
+                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None):
     """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
-    per-entry dots go to `dots2` ([slots, lists2.cap])."""
+    per-entry dots go to `dots2` ([slots, lists2.cap]).  `extra` = (compact gradient [n, d] fp32, map int32 [L*F],
+    compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows."""
     _chk(W); _chk(coef)
+    ex, exmap, excs = extra if extra is not None else (None, None, None)
+    if ex is not None:
+        _chk(ex); _chk(exmap, torch.int32)
+        assert ex.shape[-1] == W.shape[-1]
     src_bf16 = src.dtype == torch.bfloat16
     _chk(src, src.dtype)
     d = W.shape[-1]
@@ -757,7 +762,45 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), int(src_bf16), _stream())
+         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), _stream())
+
+
+def compact_columns(dead_u8: torch.Tensor):
+    """Dead-column compaction maps (clt_compact_columns).  Returns (n_pad, idx int32 [L, n_pad], map int32 [L*F]) or
+    None when no feature is dead.  One host read (the per-layer counts)."""
+    _chk(dead_u8, torch.uint8)
+    L, F = dead_u8.shape
+    counts = torch.empty(L, dtype=torch.int32, device=dead_u8.device)
+    call("clt_compact_columns", dead_u8.data_ptr(), L, F, 0, counts.data_ptr(), None, None, _stream())
+    nmax = int(counts.max())
+    if nmax == 0:
+        return None
+    n_pad = (nmax + 63) // 64 * 64
+    idx = torch.empty(L, n_pad, dtype=torch.int32, device=dead_u8.device)
+    cmap = torch.empty(L * F, dtype=torch.int32, device=dead_u8.device)
+    call("clt_compact_columns", dead_u8.data_ptr(), L, F, n_pad, counts.data_ptr(), idx.data_ptr(), cmap.data_ptr(), _stream())
+    return n_pad, idx, cmap
+
+
+def gather_cols(x: torch.Tensor, idx: torch.Tensor, fill: float) -> torch.Tensor:
+    """x: fp32 [B, L, F]; idx: int32 [L, n_pad] -> [B, L, n_pad]."""
+    _chk(x); _chk(idx, torch.int32)
+    Bn, L, F = x.shape
+    n_pad = idx.shape[1]
+    out = torch.empty(Bn, L, n_pad, dtype=torch.float32, device=x.device)
+    call("clt_gather_cols_f32", x.data_ptr(), idx.data_ptr(), Bn * L, L, F, n_pad, float(fill), out.data_ptr(), _stream())
+    return out
+
+
+def gather_rows(W: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """W: fp32 [groups, F, d]; idx: int32 [>= groups, n_pad] (group g uses row g) -> [groups, n_pad, d]."""
+    _chk(W); _chk(idx, torch.int32)
+    groups, F, d = W.shape
+    n_pad = idx.shape[1]
+    assert idx.shape[0] >= groups
+    out = torch.empty(groups, n_pad, d, dtype=torch.float32, device=W.device)
+    call("clt_gather_rows_f32", W.data_ptr(), idx.data_ptr(), groups, F, n_pad, d, out.data_ptr(), _stream())
+    return out
 
 
 def sparse_reduce_dots(dots, s: SparseLists, cross_layer: bool):

@@ -274,13 +274,28 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  *   grad_out != NULL: grad is written there and nothing else is touched; otherwise the Adam/AdamW update
  *   (same semantics as clt_adam_f32) is applied to W, m, v in place (+ optional bf16 shadow of W).
  * layer = src_layer, or (col0 + r) / F when src_layer < 0; src tensors are [B][L][d] fp32, or bf16 (uint16_t) when
- * src_bf16 != 0 (bf16 mode: halves the gather traffic; products still accumulate in fp32). */
+ * src_bf16 != 0 (bf16 mode: halves the gather traffic; products still accumulate in fp32).
+ * extra (optional, with extra_map): a dense gradient contribution for a subset of the rows — the compacted TopK-aux
+ * pass below —: grad[r,:] += extra[extra_map[col0 + r]][0:d] and colsum_out[col] += extra_colsum[extra_map[col]]
+ * wherever extra_map[...] >= 0. */
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
                             const float* coef2, const float* src2, float* dot_out, float* dot_out2, long dot_stride,
                             long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, int adamw, int step, int src_bf16, void* stream);
+                            double weight_decay, int adamw, int step, int src_bf16, const float* extra,
+                            const int32_t* extra_map, const float* extra_colsum, void* stream);
+/* Column compaction for the TopK-aux pass (clt_lightning.py:539-553: top k_aux among the DEAD features, second decoder
+ * pass): the dead columns are gathered so that the pass runs as a dense sub-problem of n_pad columns per layer.
+ *   clt_compact_columns: counts[l] = number of dead features of layer l; when idx != NULL also
+ *       idx[l][j] = j-th dead feature of layer l (ascending; -1 beyond counts[l]; n_pad entries per layer) and
+ *       map[l*F + i] = l*n_pad + position of feature i among layer l's dead features, or -1.
+ *   clt_gather_cols_f32: out[r][j] = x[r][idx[r % L][j]] (x: [rows][F], rows = tokens*L), `fill` where idx < 0.
+ *   clt_gather_rows_f32: out[g][j][0:d] = W[g][idx[g][j]][0:d] (W: [groups][F][d]; group g uses idx row g), 0 where idx < 0. */
+int clt_compact_columns(const uint8_t* dead, int L, int F, int n_pad, int32_t* counts, int32_t* idx, int32_t* map, void* stream);
+int clt_gather_cols_f32(const float* x, const int32_t* idx, int rows, int L, int F, int n_pad, float fill, float* out,
+                        void* stream);
+int clt_gather_rows_f32(const float* W, const int32_t* idx, int groups, int F, int n_pad, int d, float* out, void* stream);
 /* dval[p] = sum_{s < (cross_layer ? L - col/F : 1)} dots[s*stride + p]  — d(loss)/d(feature) per CSC entry. */
 int clt_sparse_reduce_dots_f32(const float* dots, long stride, const uint32_t* col_start, int L, int F,
                                int cross_layer, float* dval, void* stream);
