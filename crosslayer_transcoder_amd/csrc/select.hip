@@ -244,6 +244,9 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < NPT / 4; ++j) {
         const int i0 = (j * RT + tid) * 4;
+        // list output only (no dense row to write): a wave whose 256 keys of this group are all below T has nothing to do
+        if (!fr && !rank_ties &&
+            !__any(key[j * 4] >= T || key[j * 4 + 1] >= T || key[j * 4 + 2] >= T || key[j * 4 + 3] >= T)) continue;
         uint32_t before = 0;                                // ties with a lower index inside this group
         if (rank_ties) {                                    // (block-uniform branch) ordered scan: thread order, then c
             uint32_t mine = 0;
