@@ -2,10 +2,10 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units).
 gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half of a wide coalesced read stream -> x2.
 Writes profiles/pmc_traffic.json (read by bench.py for roofline.traffic) and prints a markdown table."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/pmc_{c}/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(f"gpurun_out/pmc_{c}/*/*_counter_collection.csv"), key=os.path.getmtime)
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c:
