@@ -50,6 +50,8 @@ SIGNATURES = {
     "clt_jumprelu_loss_bf16_workspace_bytes": (SZ, [I, I]),
     "clt_jumprelu_loss_bwd_bf16": (I, [P, P, P, P, F32, F32, F32, I, F32, P, P, P, P, P, I, I, P, SZ, P]),
     "clt_rowscale_add_f32": (I, [P, P, P, P, I, I, P]),
+    "clt_recon_metrics_f32": (I, [P, P, L, P, P, I, I, P, P]),
+    "clt_count_positive_f32": (I, [P, I, I, P, P]),
     "clt_column_any_positive_f32": (I, [P, I, I, P, P]),
     "clt_dead_update": (I, [P, I, L, P, L, P, P, P]),
     "clt_sparse_build_workspace_bytes": (SZ, [I, I, I]),

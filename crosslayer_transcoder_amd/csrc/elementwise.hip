@@ -445,6 +445,41 @@ __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const float* __
     s = block_sum_d(s_w, sh); if (threadIdx.x == 0) part_s[b * 3 + 2] = s;
 }
 
+// ---- logging side outputs (clt_lightning.py:131-199): per-column sums over the batch, fp64 ----------------------
+// out[j][0..5] = sum_r (yn - r)^2, sum yn, sum yn^2, sum (r*std + mean - y)^2, sum r, sum r^2   (yn = (y - mean)/std)
+__global__ __launch_bounds__(256) void recon_metrics_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv, int rows,
+                                                            int n, double* __restrict__ out) {
+    __shared__ double sh[4][64][6];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    if (j < n) {
+        const float mu = mean[j], sd = stdv[j];
+        for (int i = ty; i < rows; i += 4) {
+            const float rv = r[(long)i * n + j], yv = y[(long)i * yrs + j];
+            const float yn = (yv - mu) / sd;
+            const float e = yn - rv, er = (rv * sd + mu) - yv;
+            a[0] += (double)e * e; a[1] += (double)yn; a[2] += (double)yn * yn; a[3] += (double)er * er;
+            a[4] += (double)rv; a[5] += (double)rv * rv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh[ty][tx][q] = a[q];
+    __syncthreads();
+    if (ty == 0 && j < n)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[(long)j * 6 + q] = ((sh[0][tx][q] + sh[1][tx][q]) + sh[2][tx][q]) + sh[3][tx][q];
+}
+
+// counts[j] = #{r : feat[r][j] > 0}
+__global__ void count_positive_kernel(const float* __restrict__ f, int rows, int n, int32_t* __restrict__ counts) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int c = 0;
+    for (int r = 0; r < rows; ++r) c += f[(long)r * n + j] > 0.0f ? 1 : 0;
+    counts[j] = c;
+}
+
 // out[r*ld_out + j] = bias[j] + sum_s slabs[s*slab_stride + r*n + j]   (split-K partial results of the dense
 // cross-layer decoder: one [rows][n] slab per source layer, summed in source-layer order)
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, long total, int n, long ld_out,
@@ -636,6 +671,17 @@ int clt_jumprelu_loss_bwd_bf16(const float* x, const float* theta, const float* 
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)part, gy, n, dtheta, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)gy * n), gy, n, dnorm, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)2 * gy * n), gy, n, dbias, 0);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_recon_metrics_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,
+                          double* out, void* st) {
+    if (rows <= 0 || n <= 0 || yrs < n) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(recon_metrics_kernel, dim3((n + 63) / 64), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, out);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_count_positive_f32(const float* feat, int rows, int n, int32_t* counts, void* st) {
+    if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
+    hipLaunchKernelGGL(count_positive_kernel, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, as_stream(st), feat, rows, n, counts);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_column_any_positive_f32(const float* f, int rows, int n, uint8_t* fired, void* st) {

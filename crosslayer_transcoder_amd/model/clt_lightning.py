@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine
+from .. import metrics as _metrics
 from ..optim import FusedAdam
 from .clt import CrossLayerTranscoder
 
@@ -110,11 +111,35 @@ class CrossLayerTranscoderModule(_Base):
         """Loss + gradients through the fused engine (no autograd).  Result kept in `self.last_step`.
         With `optimizer` (a FusedAdam) the sparse regime applies Adam to the weight matrices inside its
         backward row pass; those parameters are then absent from out["grads"]."""
+        log_now = self.log_metrics_every > 0 and batch_idx % self.log_metrics_every == 0
         with torch.no_grad():
+            # (weight norms are logged from the pre-update weights, as the reference does inside training_step)
+            norms = _metrics.weight_norm_metrics(self.model) if log_now and batch.is_cuda else None
             out = engine.training_step(self, batch, batch_idx, optimizer, sparse)
-        self.last_step = out
-        self._log_terms(out["terms"])
+            self.last_step = out
+            self._log_terms(out["terms"])
+            if log_now:
+                self.log_training_metrics(out, batch, batch_idx, norms)
         return out
+
+    def log_training_metrics(self, out, batch, batch_idx, weight_norms=None):
+        """clt_lightning.py:131-280 without the host copy of the feature tensor: every value comes from device-side
+        reductions of what the step already produced (crosslayer_transcoder_amd/metrics.py)."""
+        counts = _metrics.fire_counts(out)
+        for k, v in _metrics.training_metrics(self, out, batch, counts, weight_norms).items():
+            self.log(k, v)
+        self.tokens_seen = getattr(self, "tokens_seen", 0) + batch.shape[0] * self.log_metrics_every      # :160-163
+        self.log("training/tokens_seen", self.tokens_seen)
+        if self.compute_dead_features and self.dead_features is not None:                               # :243-280
+            self.dead_features.update(counts=counts, tokens=batch.shape[0])
+            if self.global_step % self.compute_dead_features_every == 0:
+                stats = self.dead_features.compute()
+                self.log("metrics/dead_features_mean", stats["mean"])
+                for i, v in enumerate(stats.get("per_layer", [])):
+                    self.log(f"layers/dead_features/layer_{i}", v)
+                if "log_freqs" in stats:
+                    self.log("training/log_feature_density_mean", stats["log_freqs"].mean())
+                self.dead_features.reset()
 
     def training_step(self, batch, batch_idx):
         out = self.compute_step(batch, batch_idx)

@@ -460,6 +460,25 @@ def rowscale_add(W, dnorm, sq, dW, off=0):
          _chk(dW).data_ptr(), rows, d, _stream())
 
 
+def recon_metrics(r, y, mean, std):
+    """Per-column fp64 sums [L, d, 6] for the logged reconstruction metrics (see clt_recon_metrics_f32)."""
+    _chk(r); _chk(y, contiguous=False); _chk(mean); _chk(std)
+    rows, n, rs = _rows_view(y)
+    out = torch.empty(*r.shape[1:], 6, dtype=torch.float64, device=r.device)
+    call("clt_recon_metrics_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, out.data_ptr(),
+         _stream())
+    return out
+
+
+def count_positive(feat):
+    """int32 [L, F]: number of rows (tokens) in which each feature is positive."""
+    _chk(feat)
+    rows, n = feat.shape[0], feat[0].numel()
+    counts = torch.empty(feat.shape[1:], dtype=torch.int32, device=feat.device)
+    call("clt_count_positive_f32", feat.data_ptr(), rows, n, counts.data_ptr(), _stream())
+    return counts
+
+
 def column_any_positive(feat):
     _chk(feat)
     rows, n = feat.shape[0], feat[0].numel()

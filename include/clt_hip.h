@@ -170,6 +170,14 @@ int clt_rowscale_add_f32(const float* W, const float* dnorm, const float* sq, fl
  * last_active[j] = (fired[j] ? 0 : last_active[j]) + tokens ; dead[j] = last_active[j] > tokens_till_dead ;
  * dead_count[0] = sum_j dead[j]   (logged as metrics/dead_features = dead_count / n).
  * ------------------------------------------------------------------------------------------- */
+/* Logging side outputs (clt_lightning.py:131-199 log_training_metrics, metrics/dead_features.py:40-42): what the
+ * reference computes from [B,L,F] / [B,L,d] tensors copied to the host.
+ *   clt_recon_metrics_f32: out[j][0..5] (fp64) = sum_r (yn-r)^2, sum yn, sum yn^2, sum (r*std+mean-y)^2, sum r, sum r^2
+ *                          per column j of recons_norm r [rows][n]; yn = (y-mean)/std, y with row stride yrs.
+ *   clt_count_positive_f32: counts[j] = #{r : feat[r][j] > 0}  (per-feature fire counts: L0 per layer, DeadFeatures). */
+int clt_recon_metrics_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,
+                          double* out, void* stream);
+int clt_count_positive_f32(const float* feat, int rows, int n, int32_t* counts, void* stream);
 int clt_column_any_positive_f32(const float* feat, int rows, int n, uint8_t* fired, void* stream);
 int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* last_active, long tokens_till_dead,
                     uint8_t* dead, int32_t* dead_count, void* stream);

@@ -521,3 +521,53 @@ def fold_decoder_plt(W: Tensor, b: Tensor, mean: Tensor, std: Tensor) -> Tuple[T
 
 def fold_decoder_clt(Ws: List[Tensor], b: Tensor, mean: Tensor, std: Tensor) -> Tuple[List[Tensor], Tensor]:
     return [Ws[l] * std[l] for l in range(len(Ws))], b * std + mean
+
+
+# ------------------------------------------------------------------------------------------------
+# Logging side outputs: clt_lightning.py:131-199 (log_training_metrics), metrics/dead_features.py:40-60
+# ------------------------------------------------------------------------------------------------
+def training_metrics(features: Tensor, recons_norm: Tensor, mlp_out: Tensor, std: Dict[str, Tensor],
+                     params: Dict[str, Tensor], dec_kind: str) -> Dict[str, Tensor]:
+    """Every batch-dependent value log_training_metrics logs, under the reference's names (tokens_seen, the learning
+    rate and the W&B tables are host bookkeeping, not restated)."""
+    L = recons_norm.shape[1]
+    yn = standardize(mlp_out, std["out_mean"], std["out_std"])                  # :135
+    recons = destandardize(recons_norm, std["out_mean"], std["out_std"])
+    mse = (recons_norm - yn) ** 2                                               # :142
+    ss_err = ((yn - recons_norm) ** 2).sum(dim=0)                               # :144-145
+    ss_total = ((yn - yn.mean(dim=0, keepdim=True)) ** 2).sum(dim=0)            # :146-148
+    out = {"metrics/fraction_of_variance_unexplained": (ss_err / ss_total).mean()}      # :149
+    fvu_l = (ss_err / ss_total).mean(dim=-1)                                    # :151
+    for l in range(L):
+        out[f"layers/fraction_of_variance_unexplained/layer_{l}"] = fvu_l[l]
+    out["model/encoder_direction_magnitude"] = params["encoder.W"].norm(p=2, dim=1).mean()           # :166-167
+    if dec_kind == "clt":                                                        # :168-176
+        lens = torch.cat([params[f"decoder.W_{l}"].norm(p=2, dim=-1).flatten() for l in range(L)])
+    else:
+        lens = params["decoder.W"].norm(p=2, dim=-1).flatten()
+    out["model/decoder_direction_magnitude"] = lens.mean()
+    mse_l = mse.mean(dim=(0, 2))                                                # :179
+    for l in range(L):
+        out[f"layers/train_mse/layer_{l}"] = mse_l[l]
+    out["metrics/train_mse"] = mse.mean()                                       # :184
+    out["metrics/train_mse_rescaled"] = ((recons - mlp_out) ** 2).mean()        # :185
+    out["metrics/recons_standardized_std"] = recons_norm.std()                  # :189
+    active = features > 0                                                       # :139
+    out["metrics/L0_avg_per_layer"] = torch.count_nonzero(active) / (features.shape[0] * features.shape[1])   # :190-194
+    l0 = torch.count_nonzero(active, dim=(0, 2)) / features.shape[0]            # :197
+    for l in range(L):
+        out[f"layers/L0/layer_{l}"] = l0[l]
+    return out
+
+
+def dead_features_update(n_active: Tensor, n_total: Tensor, features: Tensor) -> Tuple[Tensor, Tensor]:
+    """DeadFeatures.update (metrics/dead_features.py:40-42)."""
+    return n_active + (features > 0.0).sum(dim=0), n_total + features.shape[0]
+
+
+def dead_features_compute(n_active: Tensor, n_total: Tensor) -> Dict[str, Tensor]:
+    """DeadFeatures.compute with every return_* flag on (metrics/dead_features.py:44-60)."""
+    dead = n_active == 0
+    li, fi = dead.nonzero(as_tuple=True)
+    return {"mean": dead.float().mean(), "layer_indices": li, "feature_indices": fi, "per_layer": dead.float().mean(dim=1),
+            "log_freqs": torch.clamp(torch.log10(n_active / n_total), min=-10)}

@@ -187,6 +187,7 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
             "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
     mod = build_module(case)
     mod.global_step = 5
+    mod.log_metrics_every = 0                     # (logging at step 0 would materialise the lazy fp32 features)
     with precision("bf16-mixed"):
         out = mod.compute_step(batch.cuda(), 0, sparse=False)
     c = dict(cfg); c["loss"] = dict(lc, step_frac=0.5)
@@ -206,6 +207,7 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
         assert "features" not in dict.keys(out), "the fused dense path should not materialise fp32 features"
         mod2 = build_module(case)
         mod2.global_step = 5
+        mod2.log_metrics_every = 0
         engine.FUSE_DENSE_JUMPRELU = False
         try:
             with precision("bf16-mixed"):
@@ -283,3 +285,48 @@ def test_pinned_prefetcher_and_fit_loop(golden):
     losses, _ = trainer.fit(mod, list(case["batches"]), case["max_steps"])      # fewer batches than max_steps: stops early
     for t, rec in enumerate(case["steps"]):
         assert_close(losses[t], rec["loss"], 2e-5, 1e-7, f"fit loss {t}")
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["training_step", "fused-adam-step"])
+@pytest.mark.parametrize("name", ["dbg_jumprelu_clt", "jumprelu_plt_notanh", "topk_clt_aux", "batchtopk_clt_base"])
+def test_logging_side_outputs_match_reference(name, fused, golden):
+    """Everything log_training_metrics logs at step 0 (clt_lightning.py:131-199) and the DeadFeatures statistics
+    (metrics/dead_features.py), computed on the device without the [B,L,F] host copy, vs the values the reference
+    logged (tests/golden/metrics.pt).  With Adam fused into the backward pass the weight norms still come from the
+    pre-update weights."""
+    import os
+    from crosslayer_transcoder_amd.metrics import DeadFeatures
+    from tests.build_cases import build_module
+    gm = torch.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.pt"), weights_only=True)[name]
+    case = golden(name)
+    mod = build_module(case)
+    L, F = case["last_active0"].shape
+    mod.log_metrics_every = 50
+    mod.compute_dead_features, mod.compute_dead_features_every = True, 10 ** 9
+    mod.dead_features = DeadFeatures(F, L, return_per_layer=True, return_neuron_indices=True, return_log_freqs=True)
+    mod.dead_features.reset = lambda: None        # (global_step 0 is a compute-and-reset step, as in the reference :246-280)
+    opt, sched = _opt_and_sched(mod)
+    batch = case["batches"][0].cuda()
+    if fused:
+        mod.fused_train_step(batch, 0, opt, sched)
+    else:
+        mod.training_step(batch, 0)
+    checked = 0
+    for k, want in gm["logged"].items():
+        if k.startswith(("layers/", "model/", "metrics/")) or k == "training/tokens_seen":
+            got = mod.logged[k]
+            got = got.float().cpu() if torch.is_tensor(got) else torch.tensor(float(got))
+            assert torch.allclose(got, want.float(), rtol=2e-5, atol=1e-7), (k, float(got), float(want))
+            checked += 1
+    assert checked >= 14
+    # DeadFeatures: the module updated it from the step's fire counts (batch 0); add batch 1 from a plain forward
+    df = mod.dead_features
+    mod2 = build_module(case)
+    mod2.model.initialize_standardizers(batch)
+    with torch.no_grad():
+        feat1 = mod2.model(case["batches"][1][:, 0].cuda())[1]
+    df.update(feat1)
+    assert torch.equal(df.n_active.cpu(), gm["n_active"]) and torch.equal(df.n_total.cpu(), gm["n_total"])
+    stats = df.compute()
+    for k, want in gm["dead_features"].items():
+        assert torch.allclose(stats[k].float().cpu(), want.float(), rtol=1e-6, atol=0), k
