@@ -64,6 +64,17 @@ class FeatureShard:
             dist.all_gather_into_tensor(region.view(-1), mine, group=self.group)
         return region
 
+    def all_gather_cat(self, t: torch.Tensor, dim: int) -> torch.Tensor:
+        """Concatenation over ranks of every rank's `t` along `dim` (rank order = feature order)."""
+        src = t.detach().contiguous()
+        if self._host_staged and src.is_cuda:
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, src.cpu(), group=self.group)
+        else:
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self.group)
+        return torch.cat(parts, dim=dim)
+
     def slice_features(self, t: torch.Tensor, dim: int) -> torch.Tensor:
         """This rank's slice of a full-size tensor along its feature axis."""
         return t.narrow(dim, self.f_off, self.F_local)
@@ -136,3 +147,62 @@ def shard_module(mod, shard: FeatureShard):
                 delattr(m, attr)
     mod.shard = shard
     return mod
+
+
+#: feature axis of every state-dict entry that has one (reference model/parallel.py:186-192, 235-255, 303-310)
+def _feature_axis(key: str):
+    if key in ("encoder.W", "nonlinearity.theta"):
+        return 2
+    if key == "encoder.b" or key == "decoder.W" or key.startswith("decoder.W_"):
+        return 1
+    return None
+
+
+def gather_full_state_dict(mod, shard: FeatureShard, to_cpu: bool = True):
+    """Full-size state dict of a feature-sharded model (gather-on-save): entries with a feature axis are concatenated
+    over ranks in feature order, tensor by tensor (moved to the host as they complete), the rest is rank 0's copy.
+    Collective: every rank must call it; every rank gets the result."""
+    full = {}
+    for k, v in mod.model.state_dict().items():
+        ax = _feature_axis(k)
+        if ax is None:
+            t = v.detach()
+        elif k == "encoder.W":                  # stored feature-major [L, F, d]: gather that layout, return the logical view
+            t = shard.all_gather_cat(mod.model.encoder.Wt, 1).permute(0, 2, 1)
+        else:
+            t = shard.all_gather_cat(v, ax)
+        full[k] = t.cpu() if to_cpu else t
+    return full
+
+
+def save_pretrained_sharded(mod, shard: FeatureShard, directory, fold_standardizers: bool = True):
+    """`CrossLayerTranscoder.save_pretrained` (reference clt.py:443-467) for a feature-sharded model: folding is local
+    (it scales along d_acts only and the folded biases are per feature / replicated), the weights are gathered, and
+    rank 0 writes `config.yaml` (global d_features) + `checkpoint.safetensors` with the reference's state-dict keys —
+    loadable by `from_pretrained` on one GPU or by the reference's own tooling."""
+    from pathlib import Path
+    import yaml
+    from safetensors.torch import save_file
+    model = mod.model
+    if fold_standardizers:
+        model.fold()
+    full = gather_full_state_dict(mod, shard)
+    if shard.rank == 0:
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        config = model.to_config()
+
+        def globalize(node):
+            if isinstance(node, dict):
+                for kk, vv in node.items():
+                    if kk == "d_features" and vv == shard.F_local:
+                        node[kk] = shard.F_global
+                    else:
+                        globalize(vv)
+        globalize(config)
+        config["is_folded"] = model._is_folded
+        with open(directory / "config.yaml", "w") as fh:
+            yaml.dump({"model": config}, fh)
+        save_file({k: v.contiguous() for k, v in full.items()}, directory / "checkpoint.safetensors")
+    if dist.is_initialized():
+        dist.barrier(group=shard.group)

@@ -152,6 +152,38 @@ def gpu_bf16_fused_sharded(rank, world):
             assert_close(p, ref, 1e-4, 0.3 * 1e-3, f"{kind} param {k}")
 
 
+def gpu_save_sharded(rank, world):
+    """Gather-on-save: the checkpoint written from two shards loads on one GPU and reproduces the unsharded model."""
+    import tempfile
+    from crosslayer_transcoder_amd.model import CrossLayerTranscoder
+    from crosslayer_transcoder_amd.parallel import FeatureShard, save_pretrained_sharded, shard_module
+    from tests.build_cases import build_module
+    from tests.conftest import load_golden
+    for name in ("topk_clt_aux", "jumprelu_plt_notanh"):
+        case = load_golden(name)
+        batch = case["batches"][0].cuda()
+        full = build_module(case, "cuda:0")
+        full.model.initialize_standardizers(batch)
+        with torch.no_grad():
+            want = full.model(batch[:, 0])[3]
+        part = build_module(case, "cuda:0")
+        part.model.initialize_standardizers(batch)
+        shard = FeatureShard(case["cfg"]["d_features"], keep_single=KEEP_SINGLE)
+        shard_module(part, shard)
+        obj = [tempfile.mkdtemp() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        save_pretrained_sharded(part, shard, obj[0], fold_standardizers=True)
+        loaded = CrossLayerTranscoder.from_pretrained(obj[0]).cuda()
+        assert loaded._is_folded and loaded.encoder.d_features == case["cfg"]["d_features"]
+        with torch.no_grad():
+            got = loaded(batch[:, 0])[3]
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().max())), f"{name}: reloaded sharded checkpoint"
+        sd = loaded.state_dict()
+        for k, v in full.model.state_dict().items():
+            if k in sd and "standardizer" not in k:
+                assert sd[k].shape == v.shape, k
+
+
 def sim_selection(rank, world):
     """torch restatement of the stage contract of clt_select_lists_sharded_f32 on one shard."""
     from crosslayer_transcoder_amd.parallel import FeatureShard, run_sharded_selection
@@ -270,6 +302,7 @@ def main():
                 torch.cuda.set_device(0)
             gpu_selection_ties(rank, world)
             gpu_bf16_fused_sharded(rank, world)
+            gpu_save_sharded(rank, world)
             for name in args.cases.split(","):
                 for fuse in (False, True):
                     gpu_case(name, fuse)
