@@ -22,41 +22,126 @@ __global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restric
     if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads, 4 consecutive items
-// per thread (one 16-byte load when aligned: a wave reads 1 KB contiguous), one barrier per 4096 items (the
-// per-wave totals are double buffered; the running carry lives in a register of every thread)
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads.  Per iteration the
+// block takes 16384 items as four 4096-item sub-chunks (thread t: 4 consecutive items of each, one 16-byte load when
+// aligned, so a wave reads 1 KB contiguous per load); the next iteration's loads are issued before this iteration's
+// barrier, so the single barrier per 16384 items (per-wave totals double buffered, running carry in a register of every
+// thread) never waits on memory.
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ start,
                                                      uint32_t* __restrict__ total, uint8_t* __restrict__ fired, const int32_t* __restrict__ gate, int gate_on) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
-    __shared__ uint32_t sh[2][16];
+    __shared__ uint32_t sh[2][4][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool vec = (reinterpret_cast<uintptr_t>(cnt) & 15) == 0;
+    auto load = [&](long base, uint32_t (*v)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long i0 = base + s * 4096 + (long)threadIdx.x * 4;
+            v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0u;
+            if (vec && i0 + 3 < n) { const uint4 t = *reinterpret_cast<const uint4*>(cnt + i0); v[s][0] = t.x; v[s][1] = t.y; v[s][2] = t.z; v[s][3] = t.w; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (i0 + j < n) v[s][j] = cnt[i0 + j];
+            }
+        }
+    };
     uint32_t carry = 0;
     int par = 0;
-    for (long base = 0; base < n; base += 4096, par ^= 1) {
-        const long i0 = base + (long)threadIdx.x * 4;
-        uint32_t v[4] = {0u, 0u, 0u, 0u};
-        if (vec && i0 + 3 < n) { const uint4 t = *reinterpret_cast<const uint4*>(cnt + i0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-        else {
+    uint32_t nxt[4][4];
+    load(0, nxt);
+    for (long base = 0; base < n; base += 16384, par ^= 1) {
+        uint32_t v[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (i0 + j < n) v[j] = cnt[i0 + j];
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[s][j] = nxt[s][j];
+        if (base + 16384 < n) load(base + 16384, nxt);
+        uint32_t sum[4], inc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sum[s] = v[s][0] + v[s][1] + v[s][2] + v[s][3];
+            inc[s] = sum[s];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc[s], o, 64); if (lane >= o) inc[s] += t; }
+            if (lane == 63) sh[par][s][w] = inc[s];
         }
-        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
-        uint32_t inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) sh[par][w] = inc;
         __syncthreads();
-        uint32_t wbase = 0, tot = 0;
+        uint32_t sub = carry;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const uint32_t s = sh[par][k]; if (k < w) wbase += s; tot += s; }
-        uint32_t run = carry + wbase + inc - sum;
+        for (int s = 0; s < 4; ++s) {
+            uint32_t wbase = 0, tot = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j < n) { start[i0 + j] = run; if (fired) fired[i0 + j] = v[j] > 0; run += v[j]; }
-        carry += tot;
+            for (int k = 0; k < 16; ++k) { const uint32_t x = sh[par][s][k]; if (k < w) wbase += x; tot += x; }
+            uint32_t run = sub + wbase + inc[s] - sum[s];
+            const long i0 = base + s * 4096 + (long)threadIdx.x * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < n) { start[i0 + j] = run; if (fired) fired[i0 + j] = v[s][j] > 0; run += v[s][j]; }
+            sub += tot;
+        }
+        carry = sub;
     }
     if (threadIdx.x == 0) { start[n] = carry; if (total) *total = carry; }
+}
+
+// The same scan over many workgroups, for long arrays (one CU alone streams only ~20 GB/s): chunk totals first, then
+// every chunk scans itself behind the sum of the totals before it.  `scratch`: ceil(n / 4096) words.
+__global__ __launch_bounds__(1024) void scan_totals_kernel(const uint32_t* __restrict__ cnt, int n, uint32_t* __restrict__ scratch,
+                                                            const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ uint32_t sh[16];
+    const long i0 = (long)blockIdx.x * 4096 + (long)threadIdx.x * 4;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (i0 + j < n) s += cnt[i0 + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < 16; ++k) t += sh[k]; scratch[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __restrict__ cnt, int n, const uint32_t* __restrict__ scratch,
+                                                            uint32_t* __restrict__ start, uint32_t* __restrict__ total,
+                                                            uint8_t* __restrict__ fired, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ uint32_t sh[16], shb[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t before = 0;                                  // sum of the totals of the chunks before this one
+    for (int c = threadIdx.x; c < (int)blockIdx.x; c += 1024) before += scratch[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    const long i0 = (long)blockIdx.x * 4096 + (long)threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i0 + j < n ? cnt[i0 + j] : 0u;
+    const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) sh[w] = inc;
+    if (lane == 0) shb[w] = before;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0, carry = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t x = sh[k]; if (k < w) wbase += x; tot += x; carry += shb[k]; }
+    uint32_t run = carry + wbase + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j < n) { start[i0 + j] = run; if (fired) fired[i0 + j] = v[j] > 0; run += v[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { start[n] = carry + tot; if (total) *total = carry + tot; }
+}
+
+// scratch == nullptr or a short array: the single-workgroup kernel
+static inline void launch_scan(const uint32_t* cnt, int n, uint32_t* start, uint32_t* total, uint8_t* fired, const int32_t* gate,
+                               int gate_on, uint32_t* scratch, hipStream_t st) {
+    if (!scratch || n <= 65536) {
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n, start, total, fired, gate, gate_on);
+        return;
+    }
+    const int chunks = (n + 4095) / 4096;
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(chunks), dim3(1024), 0, st, cnt, n, scratch, gate, gate_on);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(1024), 0, st, cnt, n, (const uint32_t*)scratch, start, total, fired, gate, gate_on);
 }
 
 // ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row

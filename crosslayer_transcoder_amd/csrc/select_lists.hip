@@ -480,7 +480,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
         }
         if (stage != 5) continue;
         // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, a.col_start, (uint32_t*)nullptr, a.fired, gate, 0);
+        launch_scan(col_cnt, ncols, a.col_start, nullptr, a.fired, gate, 0, (uint32_t*)long_list, st);   // (long_list is idle between the row and column sorts)
         hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, rows, L, a.cap,
                            a.col_start, col_cur, a.csc_tok, a.csc_val, a.csc_ent, gate, 0);
         hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, a.col_start, ncols, a.csc_tok, a.csc_val,

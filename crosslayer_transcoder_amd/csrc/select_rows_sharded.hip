@@ -214,8 +214,7 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
                                (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(compact_rows_kernel, wgrid, dim3(TPB), 0, st, cidx, cval, p.kk, F, L, rows, row_start, cap, ent_col,
                                ent_val, overflow);
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, col_start, (uint32_t*)nullptr, fired,
-                               (const int32_t*)nullptr, 0);
+            launch_scan(col_cnt, ncols, col_start, nullptr, fired, nullptr, 0, (uint32_t*)long_list, st);   // (long_list idle until sort_cols)
             hipLaunchKernelGGL(fill_cols_kernel, wgrid, dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap, col_start, col_cur,
                                csc_tok, csc_val, csc_ent, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val,

@@ -332,7 +332,7 @@ int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t c
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1);
     hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, row_start, ent_col, ent_val, cap, overflow, gate, 1);
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, col_cnt, ncols, col_start, (uint32_t*)nullptr, fired, gate, 1);
+    launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
                        col_start, cursor, csc_tok, csc_val, csc_ent, gate, 1);
     hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val,
