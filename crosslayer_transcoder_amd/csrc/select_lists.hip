@@ -392,7 +392,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     hipStream_t st = a.st;
     const int rows = B * L, ncols = L * F;
     if (k == 0) {                                          // topk.py:86-87: nothing selected, no threshold update
-        if (hi < 5) return CLT_OK;
+        if (hi < ((a.exhaustive & 4) ? 6 : 5)) return CLT_OK;
         if (hipMemsetAsync(a.overflow, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (a.used_fallback && hipMemsetAsync(a.used_fallback, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(a.row_start, 0, (size_t)(rows + 1) * 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
@@ -424,6 +424,8 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     const int32_t* gate = mode == 0 ? nullptr : &head->gate;
     int nbk = (int)((p.capS + TPB * 16 - 1) / (TPB * 16)); if (nbk > 512) nbk = 512; if (nbk < 1) nbk = 1;
     const dim3 cgrid(nbk, p.S);
+    const bool split = (a.exhaustive & 4) != 0;
+    const int last_stage = split ? 6 : 5;
 
     for (int stage = lo; stage <= hi; ++stage) {
         if (stage == 0) {
@@ -440,7 +442,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                    p.RS, p.ns, sample);
             hipLaunchKernelGGL(sample_kernel, dim3(p.S), dim3(TPB), 0, st, p.ns, p.rank, p.Kseg, sample, state, ctl);
         } else if (mode == 0) {
-            if (stage != 5) continue;
+            if (stage != last_stage) continue;
             int32_t* ci = (int32_t*)sidx;
             const int rc = clt_internal_topk_rows(a.x, nullptr, rows, F, k, ci, sval, a.col_mask, L, row_cnt, col_cnt, st);
             if (rc != CLT_OK) return rc;
@@ -464,10 +466,18 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
             hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head);
-        } else if (stage == 5) {
+        } else if (stage == 5 || stage == 6) {
+            // split (flags & 4, the ext entry point): stage 5 = merge the gate and publish it, stage 6 = emit + lists —
+            // the host can read the outcome flag while stage 6 still runs
+            if (stage == 5) {
+                hipLaunchKernelGGL(merge_gate_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd.world, tie_region, head);
+                if (split) {
+                    if (a.used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, a.used_fallback);
+                    continue;
+                }
+            } else if (!split) continue;
             const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
             const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
-            hipLaunchKernelGGL(merge_gate_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd.world, tie_region, head);
             hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
                                sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow);
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
@@ -478,7 +488,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
                                long_list, &head->long_rows, gate, 0);
         }
-        if (stage != 5) continue;
+        if (stage != last_stage) continue;
         // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
         launch_scan(col_cnt, ncols, a.col_start, nullptr, a.fired, gate, 0, (uint32_t*)long_list, st);   // (long_list is idle between the row and column sorts)
         hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, rows, L, a.cap,
@@ -572,11 +582,11 @@ int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, in
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                              float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                              int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
-    if (stage_lo < 0 || stage_hi > 5 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1 || !prev_T) return CLT_ERR_SHAPE;
+    if (stage_lo < 0 || stage_hi > 6 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1 || !prev_T) return CLT_ERR_SHAPE;
     if (f_off < 0 || f_off + F > F_global || !(margin > 0.0f && margin <= 1.0f)) return CLT_ERR_SHAPE;
     SelArgs a{nullptr, nullptr, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
               csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
-              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, 2, prev_T, margin};
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, 2 | 4, prev_T, margin};
     return run_stages(a, stage_lo, stage_hi);
 }
 }  // extern "C"

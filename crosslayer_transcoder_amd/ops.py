@@ -687,13 +687,34 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
         if rc != 0:
             raise CltError("clt_gemm_bf16_select", rc)
 
-    run_sharded_selection(stages, shard, S, exchange, after_stage0=gemm)
-    if int(fb) != 0:                               # the step's host read: did the bound from the last step hold?
+    run_sharded_selection(stages, shard, S, exchange, after_stage0=gemm)      # ... stage 5: outcome flag published
+    # the step's host read — did the bound from the last step hold? — goes through a side stream behind an event, so it
+    # completes while stage 6 (emit + list construction) is still running and the launch queue never drains
+    ev = torch.cuda.Event()
+    ev.record()
+    stages(6, 6)
+    side, host = _flag_reader(xs.device)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        host.copy_(fb, non_blocking=True)
+    side.synchronize()
+    if int(host) != 0:
         return None, None
     T = i32(off[6], 4 * S).view(S, 4)[:, 0].clone()
     s.used_fallback = fb
     s.kth = T
     return s, T
+
+
+_FLAG_READERS = {}
+
+
+def _flag_reader(device):
+    """(side stream, pinned int32 [1]) per device for early reads of a device flag."""
+    key = torch.device(device).index
+    if key not in _FLAG_READERS:
+        _FLAG_READERS[key] = (torch.cuda.Stream(device=device), torch.zeros(1, dtype=torch.int32).pin_memory())
+    return _FLAG_READERS[key]
 
 
 def selection_kth_keys(Bn, L, F, k, mode, device) -> torch.Tensor:

@@ -247,9 +247,11 @@ int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int
                          uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream);
 /* Batch-mode selection whose candidates come from clt_gemm_bf16_select.  The lower bound is margin * (the previous
  * step's exact k-th value, prev_T[S] as order-preserving keys: word 0 of the SegState records, exchange info 6).
- * Stage 0 prepares the workspace (then run the GEMM), stages 1..5 as clt_select_lists_sharded_f32 (workspace /
- * exchange queries with flags = 2).  used_fallback[0] != 0: the attempt is void (bound too high, overflow, too many
- * ties, previous value not positive): nothing was emitted, the caller runs the ordinary path. */
+ * Stage 0 prepares the workspace (then run the GEMM), stages 1..4 as clt_select_lists_sharded_f32 (workspace /
+ * exchange queries with flags = 2); stage 5 merges the outcome over shards and PUBLISHES used_fallback[0], stage 6 emits
+ * the selection and builds the lists — so the host can fetch the flag (side stream) while stage 6 runs.
+ * used_fallback[0] != 0: the attempt is void (bound too high, overflow, too many ties, previous value not positive):
+ * nothing is emitted, the caller runs the ordinary path. */
 int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, const uint32_t* prev_T,
                              float margin, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
