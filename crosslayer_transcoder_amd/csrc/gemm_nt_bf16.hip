@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
                                                            long sBias, int accumulate, int tilesA, int tilesB, int total, int diag,
-                                                           SelEpi se) {
+                                                           SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
@@ -80,8 +80,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     };
 
     // ---- staging addresses: per glds instruction a wave fills 8 rows x 128 B ---------------------------
-    const uint16_t* gB[4];
+    // B may be K-SEGMENTED (Bseg != nullptr): k-tiles [s*kts, (s+1)*kts) of the contraction come from the matrix at
+    // Bseg[s] (same ldb) — the cross-layer decoder's feature gradient sums over target layers, i.e. contracts over
+    // (target layer, d_acts) with one weight tensor per target layer, and is then written once instead of accumulated
+    long oB[4];
     const uint16_t* gA[4];
+    const uint16_t* bbase = B0;
     auto aim = [&](const Tile& t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -89,14 +93,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);       // logical k-chunk stored at this physical slot
             int rb = t.b0 + row; rb = rb < N ? rb : N - 1;         // clamp: rows past the edge are loaded, never stored
             int ra = t.a0 + row; ra = ra < M ? ra : M - 1;
-            gB[i] = B0 + (long)t.batch * sB + (long)rb * ldb + chunk * 8;
+            oB[i] = (long)rb * ldb + chunk * 8;
             gA[i] = A0 + (long)t.batch * sA + (long)ra * lda + chunk * 8;
         }
+        bbase = B0 + (long)t.batch * sB;
     };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
+        const uint16_t* bk = bbase + (long)kt * TK;
+        if (Bseg) { const int sg = kt / kts; bk = Bseg[sg] + (long)(kt - sg * kts) * TK; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(gB[i] + (long)kt * TK, base + (i * 8 + w) * 1024);
+        for (int i = 0; i < 4; ++i) GLDS16(bk + oB[i], base + (i * 8 + w) * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) GLDS16(gA[i] + (long)kt * TK, base + OP_BYTES + (i * 8 + w) * 1024);
     };
@@ -275,9 +282,9 @@ int persistent_grid(long nblk) {
 // to the generic kernel), or a negative error.
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st) {
+                              hipStream_t st, const uint16_t* const* Bseg, int kts) {
     const bool ok = K % TK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
-                    sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
+                    sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || aligned16(B)) && aligned16(C) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L;
     if (!ok) return 1;
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
@@ -287,9 +294,19 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
                        lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
-                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{});
+                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{}, Bseg, kts);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
+}
+
+// NT GEMM whose B operand is K-segmented: C[M][N] (+)= sum_s A[:, s*kseg:(s+1)*kseg] * Bseg[s][N][kseg]^T.  Bseg is a DEVICE array
+// of nseg device pointers (each 16-byte aligned, row stride ldb).  Fast kernel only: returns 1 when the shape does not qualify.
+extern "C" int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* Bseg, float* C, int M, int N, int nseg, int kseg, long lda,
+                                     long ldb, long ldc, const float* bias, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || nseg <= 0 || kseg <= 0 || !A || !Bseg || !C) return CLT_ERR_SHAPE;
+    if (kseg % TK) return 1;
+    return clt_internal_gemm_nt_bf16(A, nullptr, C, M, N, nseg * kseg, lda, ldb, ldc, 1, 0, 0, 0, bias, 0, accumulate, as_stream(stream),
+                                     Bseg, kseg / TK);
 }
 
 // C is never written: candidates (key >= ctl[seg].lb) go to the selection workspace.  ldc / sC only define the flat
@@ -309,7 +326,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
                        (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, 0,
-                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch});
+                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

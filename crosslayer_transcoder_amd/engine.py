@@ -173,6 +173,10 @@ class _Decoder:
 
     def dgrad(self, g):
         go = _op(g)
+        if self.clt and self.bf16:          # one K-segmented GEMM per source layer: the result is written once
+            df = ops.clt_decoder_dgrad_kseg(go, self.Wop)
+            if df is not None:
+                return df
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
 
     def wgrad(self, feat, g, grads: Dict[str, torch.Tensor], featT=None):

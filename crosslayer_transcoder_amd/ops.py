@@ -29,6 +29,20 @@ def _timed_call(tag, payload, name, *args):
     TIMING.setdefault(tag, []).append((e0, e1, payload))
 
 
+def _timed_raw(tag, payload, name, *args) -> int:
+    """Like _timed_call for entry points whose return code 1 means "shape does not qualify": returns the code."""
+    fn = getattr(lib, name)
+    if TIMING is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    if rc == 0:
+        TIMING.setdefault(tag, []).append((e0, e1, payload))
+    return rc
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -156,6 +170,33 @@ def clt_decoder_dgrad(g: torch.Tensor, Ws: List[torch.Tensor]) -> torch.Tensor:
     for l in range(L - 1, -1, -1):
         _gemm(_fn_for(g), g, l * d, _chk(Ws[l], g.dtype), 0, df, 0, Bn, (l + 1) * F, d, L * d, d, L * F, False, True,
               accumulate=(l != L - 1))
+    return df
+
+
+def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor]) -> Optional[torch.Tensor]:
+    """bf16 fast form of clt_decoder_dgrad: per source layer l' ONE GEMM contracting over (target layer l >= l', d_acts)
+    with the B operand K-segmented over the per-target-layer weight tensors — the result is written once instead of
+    accumulated over L - l' passes.  g: bf16 [B, L, d]; Ws[l]: bf16 [(l+1), F, d].  None when the shape does not qualify."""
+    Bn, L, d = g.shape
+    F = Ws[0].shape[1]
+    _chk(g, torch.bfloat16)
+    if d % 64 or F % 4 or Bn * F < 256 * 256:
+        return None
+    ptrs = []
+    for lp in range(L):
+        ptrs += [_chk(Ws[l], torch.bfloat16).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
+    table = torch.tensor(ptrs, dtype=torch.int64).to(g.device)
+    df = torch.empty(Bn, L, F, dtype=torch.float32, device=g.device)
+    off = 0
+    for lp in range(L):
+        nseg = L - lp
+        rc = _timed_raw("gemm", 2.0 * Bn * F * d * nseg, "clt_gemm_bf16_nt_kseg", g.data_ptr() + 2 * lp * d, table.data_ptr() + 8 * off,
+                        df.data_ptr() + 4 * lp * F, Bn, F, nseg, d, L * d, d, L * F, None, 0, _stream())
+        if rc == 1:
+            return None
+        if rc != 0:
+            raise CltError("clt_gemm_bf16_nt_kseg", rc)
+        off += nseg
     return df
 
 

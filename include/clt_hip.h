@@ -237,6 +237,13 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
                                  float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                                  uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* NT GEMM with a K-SEGMENTED B operand: C[M][N] (+)= sum_s A[:, s*kseg : (s+1)*kseg] * Bseg[s][N][kseg]^T (+ bias[N]).
+ * Bseg: DEVICE array of nseg device pointers (bf16 matrices, row stride ldb, 16-byte aligned).  Replaces the chain of
+ * accumulating bmm's of the cross-layer decoder's feature gradient (autograd of clt.py:334-343: d feat[:, l'] =
+ * sum_{l >= l'} g[:, l] @ W_l[l']^T, one weight tensor per target layer): the contraction runs over (target layer,
+ * d_acts) in one pass and the output is written once.  Returns 1 when the shape does not qualify (kseg % 64, alignment). */
+int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* Bseg, float* C, int M, int N, int nseg, int kseg, long lda,
+                          long ldb, long ldc, const float* bias, int accumulate, void* stream);
 /* Encoder GEMM fused with the candidate filter of the batch-mode selection (bf16 NT fast kernel only; returns 1 when
  * the shape does not qualify): C = A[M][K] * B[N][K]^T + bias is NOT stored; every element whose key is >= the lower
  * bound of its segment is appended to the candidate list of a selection workspace prepared by stage 0 of

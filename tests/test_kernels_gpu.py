@@ -520,3 +520,22 @@ def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
         for a, b, nm in ((s2, s1, "sums"), (dth2, dth1, "dtheta"), (dn2, dn1, "dnorm"), (db, ops.column_sum(dpre), "dbias")):
             a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max())), nm
+
+
+def test_clt_dgrad_k_segmented_equals_accumulating_chain(ops):
+    """clt_gemm_bf16_nt_kseg (feature gradient of the cross-layer decoder as one GEMM per source layer, K-segmented
+    over the per-target-layer weight tensors) vs the chain of accumulating GEMMs and vs an fp64 reference."""
+    B, L, d, F = 512, 3, 128, 512
+    gen = torch.Generator().manual_seed(21)
+    g = torch.randn(B, L, d, generator=gen).cuda()
+    Ws = [(torch.rand(l + 1, F, d, generator=gen) * 2 - 1).cuda() for l in range(L)]
+    go, Wo = ops.cast_bf16(g), [ops.cast_bf16(w) for w in Ws]
+    df = ops.clt_decoder_dgrad_kseg(go, Wo)
+    assert df is not None
+    ref = ops.clt_decoder_dgrad(go, Wo)
+    assert torch.allclose(df, ref, rtol=1e-5, atol=1e-4)
+    gd, want = go.double().cpu(), torch.zeros(B, L, F, dtype=torch.float64)
+    for l in range(L):
+        for lp in range(l + 1):
+            want[:, lp] += gd[:, l] @ Wo[l][lp].double().cpu().T
+    assert torch.allclose(df.double().cpu(), want, rtol=1e-4, atol=1e-3)
