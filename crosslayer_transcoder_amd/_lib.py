@@ -66,6 +66,7 @@ SIGNATURES = {
     "clt_select_rows_sharded_exchange_info": (SZ, [I, I, I, I, I, I]),
     "clt_select_rows_sharded_f32": (I, [I, I, I, I, I, P, P, I, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_gemm_bf16_nt_kseg": (I, [P, P, P, I, I, I, I, L, L, L, P, I, P]),
+    "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,
                                      P, P, SZ, P]),

@@ -65,4 +65,4 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
                            const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st);
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0);
+                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr);

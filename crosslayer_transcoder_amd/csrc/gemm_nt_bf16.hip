@@ -37,6 +37,9 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
 // Epilogue 1 ("select"): instead of storing C, every element >= the segment's lower-bound key is appended as
 // (order-preserving key, flat index batch*sC + row*ldc + col) to the candidate list of the TopK selection
 // (select_lists.hip) — the 6.4 GB pre-activation tensor is then neither written nor re-read.
+// one problem of a grouped launch (clt_gemm_bf16_nt_grouped): same M, N, K and strides, own operand / result pointers
+struct GemmGroup { long aoff; const uint16_t* b; float* c; };
+
 struct SelEpi {
     const uint32_t* ctl;          // SelCtl records of 4 words: [lb key, candidate count, -, -]
     uint32_t* cand_key; uint32_t* cand_idx; uint32_t capS;
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
                                                            long sBias, int accumulate, int tilesA, int tilesB, int total, int diag,
-                                                           SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts) {
+                                                           SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts,
+                                                           const GemmGroup* __restrict__ grp) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
@@ -94,9 +98,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             int rb = t.b0 + row; rb = rb < N ? rb : N - 1;         // clamp: rows past the edge are loaded, never stored
             int ra = t.a0 + row; ra = ra < M ? ra : M - 1;
             oB[i] = (long)rb * ldb + chunk * 8;
-            gA[i] = A0 + (long)t.batch * sA + (long)ra * lda + chunk * 8;
+            gA[i] = A0 + (grp ? grp[t.batch].aoff : (long)t.batch * sA) + (long)ra * lda + chunk * 8;
         }
-        bbase = B0 + (long)t.batch * sB;
+        bbase = grp ? grp[t.batch].b : B0 + (long)t.batch * sB;
     };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
             // transposes its 64 x 128 sub-tile through a private LDS region (four passes of 16 rows, 528-byte padded
             // rows: conflict-free b128 writes) and stores 512-byte contiguous row segments: 2 rows per wave-instruction.
-            float* C = C0 + (long)batch * sC;
+            float* C = grp ? grp[batch].c : C0 + (long)batch * sC;
             unsigned char* ebuf = nt_smem + EPI_BASE_STORE + w * (16 * EROW);
             const int er = lane >> 5, ec = (lane & 31) * 4;
             const int col = b0 + wm * 128 + ec;
@@ -282,9 +286,10 @@ int persistent_grid(long nblk) {
 // to the generic kernel), or a negative error.
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg, int kts) {
+                              hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups) {
+    const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
     const bool ok = K % TK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
-                    sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || aligned16(B)) && aligned16(C) && (!bias || aligned16(bias)) &&
+                    sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L;
     if (!ok) return 1;
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
@@ -294,7 +299,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
                        lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
-                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{}, Bseg, kts);
+                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{}, Bseg, kts, grp);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
@@ -307,6 +312,15 @@ extern "C" int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* B
     if (kseg % TK) return 1;
     return clt_internal_gemm_nt_bf16(A, nullptr, C, M, N, nseg * kseg, lda, ldb, ldc, 1, 0, 0, 0, bias, 0, accumulate, as_stream(stream),
                                      Bseg, kseg / TK);
+}
+
+// Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
+// groups: DEVICE array of {long aoff (elements); const uint16_t* B; float* C} records (all 16-byte aligned).
+extern "C" int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, int ngroups, int M, int N, int K, long lda, long ldb,
+                                        long ldc, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || ngroups <= 0 || !A || !groups) return CLT_ERR_SHAPE;
+    return clt_internal_gemm_nt_bf16(A, nullptr, nullptr, M, N, K, lda, ldb, ldc, ngroups, 0, 0, 0, nullptr, 0, 0, as_stream(stream), nullptr, 0,
+                                     groups);
 }
 
 // C is never written: candidates (key >= ctl[seg].lb) go to the selection workspace.  ldc / sC only define the flat
@@ -326,7 +340,8 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
                        (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, 0,
-                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0);
+                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0,
+                       (const GemmGroup*)nullptr);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -266,6 +266,28 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
     Bn, L, F = fo.shape
     d = WTs[0].shape[1]
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
+    # all (target, source) pairs in one persistent grouped launch, one slab per pair
+    P = L * (L + 1) // 2
+    if F % 64 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
+        slabs = torch.empty(P, Bn, d, dtype=torch.float32, device=fo.device)
+        rec, p = [], 0
+        for l in range(L):
+            wt = _chk(WTs[l], torch.bfloat16).data_ptr()
+            for lp in range(l + 1):
+                rec += [lp * F, wt + 2 * lp * d * F, slabs.data_ptr() + 4 * p * Bn * d]
+                p += 1
+        table = torch.tensor(rec, dtype=torch.int64).to(fo.device)
+        rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, torch.bfloat16).data_ptr(), table.data_ptr(), P,
+                        Bn, d, F, L * F, F, d, _stream())
+        if rc == 0:
+            p = 0
+            for l in range(L):
+                call("clt_sum_slabs_f32", slabs.data_ptr() + 4 * p * Bn * d, l + 1, Bn * d, Bn, d, L * d,
+                     (b.data_ptr() + 4 * l * d) if b is not None else None, r.data_ptr() + 4 * l * d, _stream())
+                p += l + 1
+            return r
+        if rc != 1:
+            raise CltError("clt_gemm_bf16_nt_grouped", rc)
     slabs = torch.empty(L, Bn, d, dtype=torch.float32, device=fo.device)
     for l in range(L):
         _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], torch.bfloat16), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,

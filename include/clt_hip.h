@@ -244,6 +244,12 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
  * d_acts) in one pass and the output is written once.  Returns 1 when the shape does not qualify (kseg % 64, alignment). */
 int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* Bseg, float* C, int M, int N, int nseg, int kseg, long lda,
                           long ldb, long ldc, const float* bias, int accumulate, void* stream);
+/* Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
+ * groups: DEVICE array of records {int64 aoff (elements into A); const uint16_t* B; float* C}.  Used for the dense
+ * cross-layer decoder forward (clt.py:334-343): all (target layer, source layer) pairs — 78 at L = 12 — fill the chip
+ * together instead of 12 launches of 48..576 tiles.  Returns 1 when the shape does not qualify. */
+int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, int ngroups, int M, int N, int K, long lda, long ldb,
+                             long ldc, void* stream);
 /* Encoder GEMM fused with the candidate filter of the batch-mode selection (bf16 NT fast kernel only; returns 1 when
  * the shape does not qualify): C = A[M][K] * B[N][K]^T + bias is NOT stored; every element whose key is >= the lower
  * bound of its segment is appended to the candidate list of a selection workspace prepared by stage 0 of
