@@ -78,7 +78,7 @@ SIGNATURES = {
     "clt_gather_rows_f32": (I, [P, P, I, I, I, I, P, P]),
     "clt_sparse_reduce_dots_f32": (I, [P, L, P, I, I, I, P, P]),
     "clt_sparse_scatter_dense_f32": (I, [P, P, P, I, I, P, P]),
-    "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P]),
+    "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
 ABI_VERSION = 1

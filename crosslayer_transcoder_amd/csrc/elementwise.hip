@@ -495,7 +495,10 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, lon
 // ---- K13 --------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n4, long n, float lr, float omb1, float b2, float omb2, float eps, float wd, int adamw,
-                            float step_size, float inv_sqrt_bc2, uint16_t* __restrict__ sh) {
+                            float step_size, float inv_sqrt_bc2, uint16_t* __restrict__ sh, const float* __restrict__ rdn,
+                            const float* __restrict__ rsq, int rlen) {
+    // optional per-row gradient term g += (rdn[row] / sqrt(rsq[row])) * p, row = element / rlen: the gradient that reaches
+    // the decoder weights through dec_norms (clt_lightning.py:438-446), folded in here instead of a pass of its own
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
         mm = mm + (gg - mm) * omb1;
@@ -506,7 +509,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
-        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 G = reinterpret_cast<const float4*>(g)[i];
+        if (rdn) { const long row = i * 4 / rlen; const float cf = rdn[row] / sqrtf(rsq[row]); G.x += cf * P.x; G.y += cf * P.y; G.z += cf * P.z; G.w += cf * P.w; }
         upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
         reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
         if (sh) { ushort4 h; h.x = f32_to_bf16(P.x); h.y = f32_to_bf16(P.y); h.z = f32_to_bf16(P.z); h.w = f32_to_bf16(P.w);
@@ -514,7 +518,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
     for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
         float P = p[i], M = m[i], V = v[i];
-        upd(P, g[i], M, V);
+        float G = g[i];
+        if (rdn) { const long row = i / rlen; G += rdn[row] / sqrtf(rsq[row]) * P; }
+        upd(P, G, M, V);
         p[i] = P; m[i] = M; v[i] = V;
         if (sh) sh[i] = f32_to_bf16(P);
     }
@@ -729,14 +735,15 @@ int clt_sum_slabs_f32(const float* slabs, int nslab, long slab_stride, int rows,
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, double wd,
-                 int adamw, int step, uint16_t* shadow, void* st) {
+                 int adamw, int step, uint16_t* shadow, const float* row_dnorm, const float* row_sq, int row_len, void* st) {
     if (n <= 0 || step < 1) return CLT_ERR_SHAPE;
+    if (row_dnorm && (!row_sq || row_len <= 0 || n % row_len)) return CLT_ERR_SHAPE;
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
     const float step_size = (float)(lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
     const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
-    const long n4 = vec ? n / 4 : 0;
+    const long n4 = (vec && (!row_dnorm || row_len % 4 == 0)) ? n / 4 : 0;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
-                       (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow);
+                       (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow, row_dnorm, row_sq, row_len);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 }  // extern "C"

@@ -212,9 +212,14 @@ class _Decoder:
             ops.row_sqnorm(w, sq, 0, True)
         return sq
 
-    def add_norm_grads(self, dn, sq, grads):
+    def add_norm_grads(self, dn, sq, grads, optimizer=None):
+        """Gradient through dec_norms.  With a FusedAdam the term is handed to the optimizer, whose update kernel adds
+        it on the fly (grads then hold the reconstruction part only)."""
         for l, w in enumerate(self.W32):
-            ops.rowscale_add(w, dn, sq, grads[f"decoder.W_{l}" if self.clt else "decoder.W"])
+            if optimizer is not None and hasattr(optimizer, "add_row_term") and w.is_contiguous():
+                optimizer.add_row_term(w, dn, sq)
+            else:
+                ops.rowscale_add(w, dn, sq, grads[f"decoder.W_{l}" if self.clt else "decoder.W"])
 
     # ---- sparse (list) passes -------------------------------------------------------------------
     def shadows(self):
@@ -380,6 +385,12 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                 cx = ops.compact_columns(dead)                      # one host read: the per-layer dead counts
                 if cx is not None and cx[0] > COMPACT_AUX_MAX_SHARE * F:
                     cx = None
+                if cx is not None:
+                    # gathered weights (fp32 + bf16 + bf16 transposed) + their fp32 gradients + compact activations
+                    rows_c = sum(w.shape[0] for w in D.W32) * cx[0]
+                    need = rows_c * d * 12 + Bn * L * cx[0] * 16
+                    if need > 0.8 * torch.cuda.mem_get_info(xs32.device)[0]:
+                        cx = None                                   # not enough HBM left: the activation-list form
             if cx is not None:
                 # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
                 n_pad, cidx, cmap = cx
@@ -448,7 +459,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
         D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
-        D.add_norm_grads(dn, sq, grads)
+        D.add_norm_grads(dn, sq, grads, optimizer)
         grads["decoder.b"] = ops.column_sum(g)
         if theta is not None:
             grads["nonlinearity.theta"] = dth

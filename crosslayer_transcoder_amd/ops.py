@@ -260,34 +260,49 @@ def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
     return r
 
 
+#: upper bound on the fp32 slab memory of one grouped decoder-forward launch
+GROUPED_SLAB_BYTES = 4 << 30
+
+
 def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Tensor:
     """fo: bf16 [B, L, F]; WTs[l]: bf16 [(l+1), d, F].  Per target layer one batched GEMM over its source layers
     (split-K by source layer) into fp32 slabs, summed in source-layer order (+ bias)."""
     Bn, L, F = fo.shape
     d = WTs[0].shape[1]
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
-    # all (target, source) pairs in one persistent grouped launch, one slab per pair
-    P = L * (L + 1) // 2
+    # (target, source) pairs in persistent grouped launches, one fp32 slab per pair; consecutive target layers share a
+    # launch as long as their slabs fit GROUPED_SLAB_BYTES (G32: all 78 pairs, 1 GB, one launch)
     if F % 64 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
-        slabs = torch.empty(P, Bn, d, dtype=torch.float32, device=fo.device)
-        rec, p = [], 0
-        for l in range(L):
-            wt = _chk(WTs[l], torch.bfloat16).data_ptr()
-            for lp in range(l + 1):
-                rec += [lp * F, wt + 2 * lp * d * F, slabs.data_ptr() + 4 * p * Bn * d]
-                p += 1
-        table = torch.tensor(rec, dtype=torch.int64).to(fo.device)
-        rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, torch.bfloat16).data_ptr(), table.data_ptr(), P,
-                        Bn, d, F, L * F, F, d, _stream())
-        if rc == 0:
+        slab_b = 4 * Bn * d
+        l0, ok = 0, True
+        while l0 < L and ok:
+            l1, P = l0, 0
+            while l1 < L and (P == 0 or (P + l1 + 1) * slab_b <= GROUPED_SLAB_BYTES):
+                P += l1 + 1
+                l1 += 1
+            slabs = torch.empty(P, Bn, d, dtype=torch.float32, device=fo.device)
+            rec, p = [], 0
+            for l in range(l0, l1):
+                wt = _chk(WTs[l], torch.bfloat16).data_ptr()
+                for lp in range(l + 1):
+                    rec += [lp * F, wt + 2 * lp * d * F, slabs.data_ptr() + p * slab_b]
+                    p += 1
+            table = torch.tensor(rec, dtype=torch.int64).to(fo.device)
+            rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, torch.bfloat16).data_ptr(),
+                            table.data_ptr(), P, Bn, d, F, L * F, F, d, _stream())
+            if rc == 1 and l0 == 0:
+                ok = False
+                break
+            if rc != 0:
+                raise CltError("clt_gemm_bf16_nt_grouped", rc)
             p = 0
-            for l in range(L):
-                call("clt_sum_slabs_f32", slabs.data_ptr() + 4 * p * Bn * d, l + 1, Bn * d, Bn, d, L * d,
+            for l in range(l0, l1):
+                call("clt_sum_slabs_f32", slabs.data_ptr() + p * slab_b, l + 1, Bn * d, Bn, d, L * d,
                      (b.data_ptr() + 4 * l * d) if b is not None else None, r.data_ptr() + 4 * l * d, _stream())
                 p += l + 1
+            l0 = l1
+        if ok:
             return r
-        if rc != 1:
-            raise CltError("clt_gemm_bf16_nt_grouped", rc)
     slabs = torch.empty(L, Bn, d, dtype=torch.float32, device=fo.device)
     for l in range(L):
         _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], torch.bfloat16), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,
@@ -562,16 +577,25 @@ def dead_update(fired, tokens: int, last_active, tokens_till_dead: int):
 
 # ---------------------------------------------------------------------------------------------- K13
 def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False,
-         bf16_shadow=None):
+         bf16_shadow=None, row_term=None):
+    """row_term = (dnorm, sq): adds (dnorm[r] / sqrt(sq[r])) * p to the gradient of every row r of the last dimension
+    (contiguous parameters only) inside the update."""
     for t in (p, g, m, v):                       # any dense layout, as long as all four share it
         _chk(t, contiguous=False)
         if t.stride() != p.stride() or t.shape != p.shape:
             raise ValueError("adam: p, g, m, v must share one memory layout")
     if not (p.is_contiguous() or p.permute(*sorted(range(p.dim()), key=lambda i: -p.stride(i))).is_contiguous()):
         raise ValueError("adam: parameter storage must be dense")
+    if row_term is not None:
+        if not p.is_contiguous():
+            raise ValueError("adam: a row term needs a contiguous parameter")
+        _chk(row_term[0]); _chk(row_term[1])
+        assert row_term[0].numel() >= p.numel() // p.shape[-1]
     call("clt_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), float(weight_decay), int(adamw), int(step),
-         bf16_shadow.data_ptr() if bf16_shadow is not None else None, _stream())
+         bf16_shadow.data_ptr() if bf16_shadow is not None else None,
+         row_term[0].data_ptr() if row_term is not None else None, row_term[1].data_ptr() if row_term is not None else None,
+         p.shape[-1] if row_term is not None else 0, _stream())
 
 
 # ------------------------------------------------------------------------------ sparse decoder path

@@ -20,6 +20,13 @@ def _same_layout(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
+        self._row_terms = {}
+
+    def add_row_term(self, p, dnorm, sq):
+        """The next step() adds (dnorm[r] / sqrt(sq[r])) * p[r, :] to p's gradient inside the update kernel (the
+        gradient that reaches the decoder weights through dec_norms, clt_lightning.py:438-446) — instead of a
+        separate read-modify-write pass over the gradient."""
+        self._row_terms[id(p)] = (dnorm, sq)
 
     def _state(self, p):
         st = self.state[p]
@@ -61,6 +68,6 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 g = _same_layout(p.grad, p)
                 ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
-                         group["weight_decay"], group["adamw"], None)
+                         group["weight_decay"], group["adamw"], None, self._row_terms.pop(id(p), None))
                 p._clt_version = getattr(p, "_clt_version", 0) + 1      # cached bf16 operand copies re-cast
         return loss

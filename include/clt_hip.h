@@ -186,10 +186,13 @@ int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* last_acti
  * K13  fused Adam / AdamW — clt_lightning.py:339-352 (torch.optim semantics, eps outside sqrt)
  * step counts from 1; hyper-parameters are doubles (torch derives 1-beta and the bias corrections in
  * double before rounding to fp32).  bf16_shadow (optional) receives the updated weights rounded to bf16.
+ * row_dnorm / row_sq / row_len (optional): the gradient gets the per-row term (row_dnorm[r] / sqrt(row_sq[r])) * p
+ * (r = element / row_len) before the update — what clt_rowscale_add_f32 would have added to g in a pass of its own
+ * (the gradient through dec_norms, clt_lightning.py:438-446).
  * ------------------------------------------------------------------------------------------- */
 int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, double lr, double beta1,
                  double beta2, double eps, double weight_decay, int adamw, int step, uint16_t* bf16_shadow,
-                 void* stream);
+                 const float* row_dnorm, const float* row_sq, int row_len, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sparse decoder path (K5b/K6 sparse, fused with K13) — replaces the dense bmm's of clt.py:334-343 and

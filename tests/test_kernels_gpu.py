@@ -539,3 +539,26 @@ def test_clt_dgrad_k_segmented_equals_accumulating_chain(ops):
         for lp in range(l + 1):
             want[:, lp] += gd[:, l] @ Wo[l][lp].double().cpu().T
     assert torch.allclose(df.double().cpu(), want, rtol=1e-4, atol=1e-3)
+
+
+def test_clt_decoder_fwd_grouped_launches(ops, monkeypatch):
+    """Dense cross-layer decoder forward through the grouped NT GEMM: one launch for all (target, source) pairs, several
+    launches under a small slab budget, both against an fp64 reference."""
+    B, L, d, F = 512, 4, 128, 256
+    gen = torch.Generator().manual_seed(33)
+    feat = torch.relu(torch.randn(B, L, F, generator=gen)).cuda()
+    Ws = [(torch.rand(l + 1, F, d, generator=gen) * 2 - 1).cuda() for l in range(L)]
+    bias = torch.randn(L, d, generator=gen).cuda()
+    fo = ops.cast_bf16(feat)
+    WTs = [ops.cast_transpose_bf16(w.contiguous()) for w in Ws]
+    one = ops.clt_decoder_fwd_t(fo, WTs, bias)
+    monkeypatch.setattr(ops, "GROUPED_SLAB_BYTES", 3 * 4 * B * d)      # at most 3 pairs per launch
+    many = ops.clt_decoder_fwd_t(fo, WTs, bias)
+    assert torch.equal(one, many)
+    want = torch.zeros(B, L, d, dtype=torch.float64)
+    fd = fo.double().cpu()
+    for l in range(L):
+        for lp in range(l + 1):
+            want[:, l] += fd[:, lp] @ WTs[l][lp].double().cpu().T
+        want[:, l] += bias[l].double().cpu()
+    assert torch.allclose(one.double().cpu(), want, rtol=1e-4, atol=1e-3)
