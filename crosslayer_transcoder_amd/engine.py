@@ -381,7 +381,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         S2 = g_aux = cx = None
         if kind == "topk":
             aux = mod.topk_aux
-            if COMPACT_AUX and shard is None and isinstance(aux, PerLayerTopK) and aux.k > 0:
+            if COMPACT_AUX and isinstance(aux, PerLayerTopK) and 0 < aux.k <= 2048:
                 cx = ops.compact_columns(dead)                      # one host read: the per-layer dead counts
                 if cx is not None and cx[0] > COMPACT_AUX_MAX_SHARE * F:
                     cx = None
@@ -391,11 +391,20 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                     need = rows_c * d * 12 + Bn * L * cx[0] * 16
                     if need > 0.8 * torch.cuda.mem_get_info(xs32.device)[0]:
                         cx = None                                   # not enough HBM left: the activation-list form
+                if shard is not None:                               # both forms hold collectives: every rank takes the same one
+                    flag = torch.tensor([0 if cx is None else 1], dtype=torch.int32, device=xs32.device)
+                    if int(shard.all_reduce_min(flag)) == 0:
+                        cx = None
             if cx is not None:
                 # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
                 n_pad, cidx, cmap = cx
-                feat_c = ops.topk_rows(ops.gather_cols(pre, cidx, float("-inf")), min(aux.k, n_pad))
-                Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), None, clt=D.clt)
+                pre_c = ops.gather_cols(pre, cidx, float("-inf"))
+                if shard is None:
+                    feat_c = ops.topk_rows(pre_c, min(aux.k, n_pad))
+                else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
+                    Sc = ops.select_rows_sharded(pre_c, aux.k, shard, local_columns=True)
+                    feat_c = ops.sparse_scatter_dense(Sc, Sc.csc_val)
+                Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
                 aux_r = Dc.fwd(feat_c)
             else:
                 S2 = _select_lists(aux, pre, dead, shard)

@@ -815,12 +815,14 @@ def selection_kth_keys(Bn, L, F, k, mode, device) -> torch.Tensor:
 
 
 def select_rows_sharded(x: torch.Tensor, k: int, shard, col_mask: Optional[torch.Tensor] = None,
-                        cap: Optional[int] = None) -> SparseLists:
-    """Feature-sharded PerLayerTopK: k of shard.F_global per (b, l) row; x = this rank's [B, L, F_local]."""
+                        cap: Optional[int] = None, local_columns: bool = False) -> SparseLists:
+    """Feature-sharded PerLayerTopK: k of shard.F_global per (b, l) row; x = this rank's [B, L, F_local].
+    local_columns: x holds an arbitrary rank-local subset of columns in feature order (the compacted dead columns of
+    the aux pass; widths may differ between ranks) — the exchange buffers depend on rows and k only."""
     from .parallel import run_sharded_rows_selection
     _chk(x)
     Bn, L, F = x.shape
-    assert F == shard.F_local
+    assert local_columns or F == shard.F_local
     if k > shard.F_global:
         raise AssertionError("k must be <= d_features")
     if min(k, F) > 2048:

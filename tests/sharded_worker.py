@@ -303,9 +303,16 @@ def main():
             gpu_selection_ties(rank, world)
             gpu_bf16_fused_sharded(rank, world)
             gpu_save_sharded(rank, world)
+            from crosslayer_transcoder_amd import engine
             for name in args.cases.split(","):
                 for fuse in (False, True):
                     gpu_case(name, fuse)
+                    if "aux" in name:       # the aux pass as a compacted dense sub-problem, forced at these small sizes
+                        share, engine.COMPACT_AUX_MAX_SHARE = engine.COMPACT_AUX_MAX_SHARE, 1e9
+                        try:
+                            gpu_case(name, fuse)
+                        finally:
+                            engine.COMPACT_AUX_MAX_SHARE = share
         print(f"rank {rank}: ok", flush=True)
     finally:
         dist.destroy_process_group()
