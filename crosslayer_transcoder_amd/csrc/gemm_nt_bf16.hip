@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
     const int nk = (diag & 2) ? 0 : K / TK;
 
+    bool stores_after_prefetch = false;
     int vb = blockIdx.x;
     Tile t = decode(vb);
     aim(t);
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first k-tile (staged before the previous tile's epilogue)
+        // first k-tile (staged before the previous tile's epilogue).  Vector-memory operations retire in issue order, so
+        // after an interior tile's store epilogue (exactly 32 stores per lane, no loads) the prefetch is complete once all
+        // but the 32 youngest operations are: the stores keep draining under the main loop
+        if (stores_after_prefetch) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
@@ -256,16 +261,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                     const int row = a0 + wn * 64 + n * 16 + lr;
                     f32x4 v = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4);
                     if (row < M && col < N) {
-                        float* dst = C + (long)row * ldc + col;
+                        // (global address space spelled out: C may come from the group table, and generic-pointer stores
+                        // would be flat_store — slower, and outside the in-order vmcnt accounting used at the loop top)
+                        typedef __attribute__((address_space(1))) f32x4 gvec;
+                        gvec* dst = (gvec*)(C + (long)row * ldc + col);
                         v += bv;
-                        if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); v += old; }
-                        if (diag & 1) { asm volatile("" ::"v"(v)); } else *reinterpret_cast<f32x4*>(dst) = v;
+                        if (accumulate) { const f32x4 old = *dst; v += old; }
+                        if (diag & 1) { asm volatile("" ::"v"(v)); } else *dst = v;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
         if (!more) break;
+        stores_after_prefetch = EPI == 0 && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
         vb = nvb;
     }
 }
