@@ -98,14 +98,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             int rb = t.b0 + row; rb = rb < N ? rb : N - 1;         // clamp: rows past the edge are loaded, never stored
             int ra = t.a0 + row; ra = ra < M ? ra : M - 1;
             oB[i] = (long)rb * ldb + chunk * 8;
-            gA[i] = A0 + (grp ? grp[t.batch].aoff : (long)t.batch * sA) + (long)ra * lda + chunk * 8;
+            gA[i] = A0 + ((EPI == 0 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)ra * lda + chunk * 8;
         }
-        bbase = grp ? grp[t.batch].b : B0 + (long)t.batch * sB;
+        bbase = (EPI == 0 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB;
     };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
         const uint16_t* bk = bbase + (long)kt * TK;
-        if (Bseg) { const int sg = kt / kts; bk = Bseg[sg] + (long)(kt - sg * kts) * TK; }
+        if (EPI == 0 && Bseg) { const int sg = kt / kts; bk = Bseg[sg] + (long)(kt - sg * kts) * TK; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) GLDS16(bk + oB[i], base + (i * 8 + w) * 1024);
 #pragma unroll
