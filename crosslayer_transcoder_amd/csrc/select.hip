@@ -94,7 +94,8 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
 // largest (k <= 1024), then over the few candidates >= that bound (compacted into LDS).  No LDS atomics on the data,
 // so no contention on the handful of exponent bins that nearly all pre-activations share.
 // ------------------------------------------------------------------------------------------------
-constexpr int RT = 1024, RW = RT / 64, RCAP = 4096;
+constexpr int RT = 1024, RW = RT / 64, RCAP = 2048;
+extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf_raw[];   // the next row, filled by LDS-DMA
 
 // m-th largest of the 64 values one wave holds (one per lane): binary search on the key bits, two bits per step, counted
 // with ballots — scalar work only, no LDS, no barrier.
@@ -115,22 +116,37 @@ template <int NPT>
 __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
                                                            int32_t* __restrict__ idx_out, float* __restrict__ val_out,
                                                            const uint8_t* __restrict__ col_mask, int L,
-                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt) {
+                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows) {
     __shared__ uint2 red[2][RW];
     __shared__ uint32_t ckey[RCAP];
     __shared__ uint32_t wtot[RW];
     __shared__ uint32_t wlb[RW];
     __shared__ uint32_t step_cnt[16][4];                   // block-wide search: per step the counts of 3 thresholds
-    __shared__ uint32_t cursor, Tsh;
-    __shared__ int32_t oidx[MAXK_COMPACT];
-    __shared__ float oval[MAXK_COMPACT];
+    __shared__ uint32_t cursor, Tsh, cnt_sh[2];
+    __shared__ int32_t oidx[1024];
+    __shared__ float oval[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long row = blockIdx.x;
-    const float* xr = x + row * F;
+    // Persistent block: rows blockIdx.x, + gridDim.x, ...  While a row is processed out of registers the next one streams
+    // into LDS by DMA (global_load_lds, 16 bytes per lane, no registers), so the HBM read overlaps the selection work.
+    float* rowbuf = reinterpret_cast<float*>(rowbuf_raw);
+    auto prefetch = [&](long r) {
+        const float* src = x + r * F;
+#pragma unroll
+        for (int j = 0; j < NPT / 4; ++j) {
+            const int i0 = (j * RT + tid) * 4;
+            if (i0 < F)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0),
+                                                 (__attribute__((address_space(3))) void*)(rowbuf_raw + (size_t)(j * RT + w * 64) * 16), 16, 0, 0);
+        }
+    };
+    prefetch(blockIdx.x);
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
     const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
     int parity = 0;
     if (tid < 64) step_cnt[tid >> 2][tid & 3] = 0;
     if (tid == 0) cursor = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // this row has landed in LDS (every wave's DMA pieces)
     // element e of this thread has index ((e / 4) * RT + tid) * 4 + e % 4; keys of positions >= F are 0 (below every real key)
     uint32_t key[NPT];
     uint32_t tmax = 0;
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
         const int i0 = (j * RT + tid) * 4;
         const bool in = i0 < F;
         const int ic = in ? i0 : 0;                            // branch-free: out-of-range groups re-read the row start
-        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
+        const float4 v = *reinterpret_cast<const float4*>(rowbuf + ic);
         float a[4] = {v.x, v.y, v.z, v.w};
         if (mk) {
             const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
@@ -148,6 +164,8 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const uint32_t kk = in ? f32_key(a[c]) : 0u; key[j * 4 + c] = kk; tmax = max(tmax, kk); }
     }
+    __syncthreads();                                        // every thread holds its keys: the buffer may be refilled
+    if (row + gridDim.x < nrows) prefetch(row + gridDim.x);
     // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
     // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
     uint32_t LB = 0;
@@ -181,8 +199,10 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
         __syncthreads();
         if (total <= 64u) {                                 // the usual case for k << F: one wave finishes the search alone
             if (w == 0) {
-                const uint32_t t = wave_kth((uint32_t)lane < total ? ckey[lane] : 0u, (uint32_t)k);
-                if (lane == 0) Tsh = t;
+                const uint32_t ckl = (uint32_t)lane < total ? ckey[lane] : 0u;
+                const uint32_t t = wave_kth(ckl, (uint32_t)k);
+                const uint32_t g1 = (uint32_t)__popcll(__ballot(ckl > t)), e1 = (uint32_t)__popcll(__ballot(ckl == t && (uint32_t)lane < total));
+                if (lane == 0) { Tsh = t; cnt_sh[0] = g1; cnt_sh[1] = e1; }     // every key >= T is a candidate (T >= LB)
             }
         } else {                                            // all waves count, one LDS atomic per wave, threshold and step
             uint32_t ck[RCAP / RT];
@@ -225,18 +245,21 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             if (sum >= (uint32_t)k) T = cand;
         }
     }
-    // counts above / at T
-    uint32_t cgt = 0, ceq = 0;
-#pragma unroll
-    for (int e = 0; e < NPT; ++e) { cgt += key[e] > T ? 1u : 0u; ceq += key[e] == T ? 1u : 0u; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cgt += __shfl_xor(cgt, o, 64); ceq += __shfl_xor(ceq, o, 64); }
-    if (lane == 0) red[parity][w] = make_uint2(cgt, ceq);
-    __syncthreads();
+    // counts above / at T (the single-wave search already has them)
     uint32_t ngt = 0, neq = 0;
+    if (total <= 64u) { ngt = cnt_sh[0]; neq = cnt_sh[1]; }
+    else {
+        uint32_t cgt = 0, ceq = 0;
 #pragma unroll
-    for (int i = 0; i < RW; ++i) { const uint2 r = red[parity][i]; ngt += r.x; neq += r.y; }
-    parity ^= 1;
+        for (int e = 0; e < NPT; ++e) { cgt += key[e] > T ? 1u : 0u; ceq += key[e] == T ? 1u : 0u; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cgt += __shfl_xor(cgt, o, 64); ceq += __shfl_xor(ceq, o, 64); }
+        if (lane == 0) red[parity][w] = make_uint2(cgt, ceq);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RW; ++i) { const uint2 r = red[parity][i]; ngt += r.x; neq += r.y; }
+        parity ^= 1;
+    }
     const uint32_t krem = (uint32_t)k - ngt;
     const bool rank_ties = (neq != krem) && (key_f32(T) > 0.0f);
     uint32_t running = 0;                                   // ties before this group of 4 * RT indices
@@ -292,6 +315,8 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
                 idx_out[row * k + pos] = me; val_out[row * k + pos] = oval[e];
             } else { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
         }
+    }
+    __syncthreads();                                        // the per-row LDS state is reset at the top of the next row
     }
 }
 
@@ -419,10 +444,18 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         if (row_cnt && hipMemsetAsync(row_cnt, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         return CLT_OK;
     }
-    const bool reg_ok = F % 4 == 0 && F <= 32 * RT && aligned16(x) && (!feat || aligned16(feat)) &&
+    const bool reg_ok = F % 4 == 0 && F <= 32 * RT && (!idx_out || k <= 1024) && aligned16(x) && (!feat || aligned16(feat)) &&
                         (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !getenv("CLT_TOPK_ROWS_V1");
     if (reg_ok) {
-#define TKR(NPT_) hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(rows), dim3(RT), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0; hipDeviceProp_t pr;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        }
+        const int grid = rows < cus ? rows : cus;
+        const size_t dyn = (size_t)((F + 4095) / 4096) * 4096 * 4;           // whole 16 KB DMA rounds
+#define TKR(NPT_) do { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_reg_kernel<NPT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return CLT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows); } while (0)
         const int per = (F + RT - 1) / RT;
         if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 16) TKR(16); else TKR(32);
 #undef TKR
