@@ -1,5 +1,5 @@
 import sys, torch, argparse
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, crosslayer_transcoder_amd as cta
 for ds in (1, 3):
     args = argparse.Namespace(layers=12, d_acts=768, features=32768, k=16, nonlinearity="topk", decoder="clt", aux=True, batch=4096, dead_steps=ds, shard_rehearsal=False)
