@@ -182,8 +182,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
             if (tid == 0) scnt[0] = 0;
             __syncthreads();
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const float lbf = key_f32(lb);                    // fast reject in float: !(v < lbf) also lets NaNs through
+            float lbf = key_f32(lb);                          // fast reject in float: !(v < lbf) also lets NaNs through
+            if (diag & 32) lbf = INFINITY;                    // (ablation: nothing passes the fast reject)
+            if (diag & 16) {                                  // (ablation: no epilogue work at all)
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(acc[m][n]));
+                if (!more) break;
+                vb = nvb;
+                continue;
+            }
             f32x4 bv[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -201,32 +210,22 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                     const bool in = row < M && col < N;
                     const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
                     if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
-                    uint32_t key[4]; bool pr[4]; unsigned long long bm[4]; uint32_t tot = 0;
+                    // rare (about 0.1 % of the elements): each lane appends its own candidates, one LDS atomic apiece
+                    if (maybe) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        key[c] = f32_key(v[c]);
-                        pr[c] = in && key[c] >= lb;
-                        bm[c] = __ballot(pr[c]);
-                        tot += (uint32_t)__popcll(bm[c]);
-                    }
-                    if (tot == 0) continue;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&scnt[0], tot);
-                    base = __shfl(base, 0, 64);
-                    uint32_t off = base;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) off += (uint32_t)__popcll(bm[c] & lt);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (pr[c]) {
-                            const uint32_t fi = flat_row + (uint32_t)(col + c);
-                            if (off < (uint32_t)ESTG) { skey[off] = key[c]; sidx[off] = fi; }
-                            else {                               // staging full (pathological tile): straight to the global list
-                                const uint32_t pos = atomicAdd(gcnt, 1u);
-                                if (pos < se.capS) { ck[pos] = key[c]; ci[pos] = fi; }
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t key = f32_key(v[c]);
+                            if (key >= lb) {
+                                const uint32_t fi = flat_row + (uint32_t)(col + c);
+                                const uint32_t off = atomicAdd(&scnt[0], 1u);
+                                if (off < (uint32_t)ESTG) { skey[off] = key; sidx[off] = fi; }
+                                else {                           // staging full (pathological tile): straight to the global list
+                                    const uint32_t pos = atomicAdd(gcnt, 1u);
+                                    if (pos < se.capS) { ck[pos] = key; ci[pos] = fi; }
+                                }
                             }
-                            ++off;
                         }
+                    }
                 }
             }
             __syncthreads();
@@ -348,7 +347,8 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
-                       (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, 0,
+                       (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk,
+                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0,
                        SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0,
                        (const GemmGroup*)nullptr);
     CLT_LAUNCH_CHECK();
