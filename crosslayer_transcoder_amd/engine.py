@@ -187,6 +187,12 @@ class _Decoder:
         if self.bf16:
             fT = featT if featT is not None else ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
             gT = ops.transpose_cast_2d(g).view(L, d, Bn)             # [L, d, B]
+            if self.clt and not any(f"decoder.W_{l}" in grads for l in range(L)):
+                outs = [torch.empty(l + 1, F, d, dtype=torch.float32, device=g.device) for l in range(L)]
+                if ops.clt_wgrad_t_grouped(fT, gT, outs):           # all (target, source) pairs in one persistent launch
+                    for l in range(L):
+                        grads[f"decoder.W_{l}"] = outs[l]
+                    return
             if self.clt:
                 for l in range(L):
                     k = f"decoder.W_{l}"

@@ -321,6 +321,31 @@ def wgrad_t(aT: torch.Tensor, bT: torch.Tensor, out: torch.Tensor, batch: int, s
     return out
 
 
+def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Tensor]) -> bool:
+    """Cross-layer decoder weight gradients in ONE grouped launch: outs[l][l'] [F, d] = fT[l'] [F, B] @ gT[l] [d, B]^T for all
+    l' <= l.  fT: bf16 [L, F, B], gT: bf16 [L, d, B] (token-minor operands), outs[l]: fp32 [(l+1), F, d] (overwritten).
+    False when the shape does not qualify (the caller then runs the per-target-layer launches)."""
+    L, F, Bn = fT.shape
+    d = gT.shape[1]
+    _chk(fT, torch.bfloat16); _chk(gT, torch.bfloat16)
+    if Bn % 64 or d % 4 or F * d < 256 * 256:
+        return False
+    rec = []
+    for l in range(L):
+        _chk(outs[l])
+        for lp in range(l + 1):
+            rec += [lp * F * Bn, gT.data_ptr() + 2 * l * d * Bn, outs[l].data_ptr() + 4 * lp * F * d]
+    table = torch.tensor(rec, dtype=torch.int64).to(fT.device)
+    P = L * (L + 1) // 2
+    rc = _timed_raw("gemm", 2.0 * F * d * Bn * P, "clt_gemm_bf16_nt_grouped", fT.data_ptr(), table.data_ptr(), P, F, d, Bn, Bn, Bn, d,
+                    _stream())
+    if rc == 1:
+        return False
+    if rc != 0:
+        raise CltError("clt_gemm_bf16_nt_grouped", rc)
+    return True
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     _chk(x)
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
