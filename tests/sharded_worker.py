@@ -279,6 +279,78 @@ def sim_selection(rank, world):
         assert mine == want, f"trial {trial} rank {rank}: sharded selection differs from the oracle"
 
 
+def sim_rows_selection(rank, world):
+    """torch restatement of the stage contract of clt_select_rows_sharded_f32 on one shard: eight 4-bit radix rounds
+    over the order-preserving keys (per-row bucket counts all-reduced), then the per-row tie counts all-gathered; ties
+    are taken in rank order = global feature order."""
+    from crosslayer_transcoder_amd.parallel import FeatureShard, run_sharded_rows_selection
+    from oracle import clt_oracle as O
+
+    def key_of(x):
+        u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        u = torch.where(u == 0x80000000, torch.zeros_like(u), u)
+        return torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u | 0x80000000)
+
+    for trial, (B, L, F, k, ties) in enumerate([(5, 3, 16, 3, False), (4, 2, 24, 5, True), (3, 1, 8, 8, False), (6, 2, 12, 1, True)]):
+        g = torch.Generator().manual_seed(200 + trial)
+        x = torch.randn(B, L, F, generator=g)
+        if ties:
+            x = torch.randint(0, 3, (B, L, F), generator=g).float() + 0.5
+        shard = FeatureShard(F, rank=rank, world=world)
+        Fl = shard.F_local
+        xl = x[:, :, shard.f_off:shard.f_off + Fl].contiguous()
+        rows = B * L
+        keys = key_of(xl).reshape(rows, Fl)
+        ex = {"counts": torch.zeros(rows * 16, dtype=torch.int32), "ties": torch.zeros(world, rows, dtype=torch.int32)}
+        st = {"prefix": torch.zeros(rows, dtype=torch.int64), "mask": torch.zeros(rows, dtype=torch.int64),
+              "krem": torch.full((rows,), k, dtype=torch.int64)}
+        result = {}
+
+        def find(rnd):
+            shift = 28 - 4 * rnd
+            cnt = ex["counts"].view(rows, 16).to(torch.int64)
+            for r in range(rows):
+                cum = 0
+                for b in range(15, -1, -1):
+                    if cum + int(cnt[r, b]) >= int(st["krem"][r]):
+                        st["prefix"][r] |= b << shift
+                        st["mask"][r] |= 0xF << shift
+                        st["krem"][r] -= cum
+                        break
+                    cum += int(cnt[r, b])
+            ex["counts"].zero_()
+
+        def count(rnd):
+            shift = 28 - 4 * rnd
+            match = (keys & st["mask"][:, None]) == st["prefix"][:, None]
+            digit = (keys >> shift) & 0xF
+            c = torch.zeros(rows, 16, dtype=torch.int32)
+            for b in range(16):
+                c[:, b] = (match & (digit == b)).sum(1).to(torch.int32)
+            ex["counts"] += c.reshape(-1)
+
+        def stages(lo, hi):
+            for s in range(lo, hi + 1):
+                if s <= 7:
+                    if s > 0:
+                        find(s - 1)
+                    count(s)
+                elif s == 8:
+                    find(7)
+                    ex["ties"][rank] = (keys == st["prefix"][:, None]).sum(1).to(torch.int32)
+                else:
+                    T = st["prefix"][:, None]
+                    before = ex["ties"][:rank].sum(0).to(torch.int64)                       # ties on lower ranks
+                    eq = keys == T
+                    local_rank = torch.cumsum(eq.to(torch.int64), 1) - 1
+                    sel = (keys > T) | (eq & ((before[:, None] + local_rank) < st["krem"][:, None]))
+                    result["feat"] = torch.where(sel, xl.reshape(rows, Fl).clamp_min(0.0), torch.zeros(())).reshape(B, L, Fl)
+
+        run_sharded_rows_selection(stages, shard, ex)
+        want = O.per_layer_topk_fwd(x, k)[0][:, :, shard.f_off:shard.f_off + Fl]
+        assert torch.equal(result["feat"], want), f"rows trial {trial} rank {rank}: sharded per-row selection differs from the oracle"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sim", action="store_true")
@@ -297,6 +369,7 @@ def main():
     try:
         if args.sim:
             sim_selection(rank, world)
+            sim_rows_selection(rank, world)
         else:
             if args.backend == "gloo":
                 torch.cuda.set_device(0)

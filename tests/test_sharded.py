@@ -22,8 +22,9 @@ def _launch(extra, nproc=2, timeout=300, port=29513):
 
 
 def test_sharded_selection_schedule_gloo_cpu():
-    """Collective schedule of the sharded BatchTopK selection (lower-bound MIN, histogram SUMs, tie gather, global
-    tie order) against the oracle, two CPU ranks."""
+    """Collective schedules of the sharded selections — BatchTopK (lower-bound MIN, histogram SUMs, tie gather, global
+    tie order) and per-row TopK (eight 4-bit radix rounds of all-reduced bucket counts, tie-count gather) — against the
+    oracle, two CPU ranks over gloo."""
     _launch(["--sim"])
 
 
