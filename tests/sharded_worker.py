@@ -107,6 +107,23 @@ def gpu_selection_ties(rank, world):
                         f"layer k={k} ties={tie_heavy}"
 
 
+def gpu_list_capacity_overflow(rank, world):
+    """A shard whose share of the selection exceeds its list capacity: all ranks redo the selection with full capacity."""
+    from crosslayer_transcoder_amd import ops
+    from crosslayer_transcoder_amd.parallel import FeatureShard
+    from oracle import clt_oracle as O
+    g = torch.Generator().manual_seed(5)
+    B, L, F, k = 16, 2, 64, 4
+    x = torch.randn(B, L, F, generator=g)
+    x[:, :, : F // max(world, 1)] += 10.0                       # every selected entry lives on rank 0
+    shard = FeatureShard(F, keep_single=KEEP_SINGLE)
+    xl = shard.slice_features(x, 2).contiguous().cuda()
+    S = ops.select_lists_sharded(xl, k, ops.SELECT_BATCH, shard, torch.zeros(1, device="cuda"), 0.1, None, cap=8)
+    assert S.cap == k * B * L and int(S.overflow) == 0
+    ref = O.batch_topk_fwd(x, k)[0]
+    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2))
+
+
 def gpu_bf16_fused_sharded(rank, world):
     """bf16 mode under sharding, including the encoder GEMM fused with the candidate filter (steps >= 1): the sharded
     run must track the unsharded run of the same full model (same per-element GEMM sums; only the all-reduce changes
@@ -374,6 +391,7 @@ def main():
             if args.backend == "gloo":
                 torch.cuda.set_device(0)
             gpu_selection_ties(rank, world)
+            gpu_list_capacity_overflow(rank, world)
             gpu_bf16_fused_sharded(rank, world)
             gpu_save_sharded(rank, world)
             from crosslayer_transcoder_amd import engine
