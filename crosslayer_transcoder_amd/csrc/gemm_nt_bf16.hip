@@ -10,6 +10,7 @@
 // bits 1..3 of the row — applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads —
 // which spreads the 16 rows of a fragment over all 16 slots of the 256-byte bank row.  Blocks are remapped so
 // that each XCD (own L2) works on a contiguous range of tiles.
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 
@@ -26,13 +27,17 @@ constexpr int ESTG = 2048;                              // select epilogue: bloc
 // while buffer 0 already receives the next tile's first k-tile, so its scratch starts at 64 KiB (store epilogue:
 // 8 waves x 16 rows x 528 B = 66 KiB) or above both buffers (select epilogue: key/index staging, 16 KiB + counters).
 constexpr int EPI_BASE_STORE = STAGE_BYTES, EPI_BASE_SELECT = 2 * STAGE_BYTES;
-constexpr int LDS_BYTES = EPI_BASE_SELECT + ESTG * 8 + 64;
-static_assert(EPI_BASE_STORE + 8 * 16 * EROW <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
+constexpr int BIAS_BASE = EPI_BASE_SELECT + ESTG * 8 + 64;   // two 1 KiB slots: the tile's 256 bias values (tile parity)
+constexpr int LDS_BYTES = BIAS_BASE + 2 * 1024;
+static_assert(EPI_BASE_STORE + 8 * 16 * EROW <= BIAS_BASE && LDS_BYTES <= 160 * 1024, "LDS");
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
 
 #define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+// block barrier that orders LDS traffic only (no wait for global loads / stores / DMA pieces in flight)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Epilogue 1 ("select"): instead of storing C, every element >= the segment's lower-bound key is appended as
 // (order-preserving key, flat index batch*sC + row*ldc + col) to the candidate list of the TopK selection
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                                                            long sBias, int accumulate, int tilesA, int tilesB, int total, int diag,
                                                            SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts,
                                                            const GemmGroup* __restrict__ grp) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
     const int fr = lane & 15, fq = lane >> 4;
@@ -87,29 +92,50 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     // B may be K-SEGMENTED (Bseg != nullptr): k-tiles [s*kts, (s+1)*kts) of the contraction come from the matrix at
     // Bseg[s] (same ldb) — the cross-layer decoder's feature gradient sums over target layers, i.e. contracts over
     // (target layer, d_acts) with one weight tensor per target layer, and is then written once instead of accumulated
-    long oB[4];
-    const uint16_t* gA[4];
-    const uint16_t* bbase = B0;
+    // The DMA pieces are MUBUF (buffer_load ... lds), not global_load_lds: with FLAT-encoded LDS-DMA in flight the
+    // compiler turns every LDS wait into lgkmcnt(0), which would serialise the pipelined fragment reads below.  Buffer
+    // descriptors are rebased per tile (base = first row of the tile), so the per-lane 32-bit offsets stay small.
+    int vB[4], vA[4];
+    __amdgpu_buffer_rsrc_t rB, rA;
+    long brow0 = 0;
+    auto rsrc = [](const uint16_t* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p), 0, -1, 0x00020000); };
     auto aim = [&](const Tile& t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 8 + w) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);       // logical k-chunk stored at this physical slot
-            int rb = t.b0 + row; rb = rb < N ? rb : N - 1;         // clamp: rows past the edge are loaded, never stored
-            int ra = t.a0 + row; ra = ra < M ? ra : M - 1;
-            oB[i] = (long)rb * ldb + chunk * 8;
-            gA[i] = A0 + ((EPI == 0 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)ra * lda + chunk * 8;
+            int rb = t.b0 + row; rb = (rb < N ? rb : N - 1) - t.b0; // clamp: rows past the edge are loaded, never stored
+            int ra = t.a0 + row; ra = (ra < M ? ra : M - 1) - t.a0;
+            vB[i] = (int)(((long)rb * ldb + chunk * 8) * 2);
+            vA[i] = (int)(((long)ra * lda + chunk * 8) * 2);
         }
-        bbase = (EPI == 0 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB;
+        brow0 = (long)t.b0 * ldb;
+        rA = rsrc(A0 + ((EPI == 0 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
+        rB = rsrc(((EPI == 0 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
     };
+    typedef __attribute__((address_space(3))) void lds_void;
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
-        const uint16_t* bk = bbase + (long)kt * TK;
-        if (EPI == 0 && Bseg) { const int sg = kt / kts; bk = Bseg[sg] + (long)(kt - sg * kts) * TK; }
+        int sob = kt * (TK * 2);
+        __amdgpu_buffer_rsrc_t rb = rB;
+        if (EPI == 0 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(bk + oB[i], base + (i * 8 + w) * 1024);
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i], sob, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(gA[i] + (long)kt * TK, base + OP_BYTES + (i * 8 + w) * 1024);
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i], kt * (TK * 2), 0, 0);
+    };
+
+    // The tile's bias slice rides along as a ninth DMA piece of wave 0 (columns past N read as zero through the
+    // descriptor's bound): the epilogues then read it from LDS, so no global load is pending anywhere near the stores —
+    // a pending load makes the compiler put a full vmcnt(0) in front of every store of the epilogue.
+    auto stage_bias = [&](const Tile& t, int slot) {
+        if (bias0 && w == 0) {
+            __amdgpu_buffer_rsrc_t r =     // (not const: a const-qualified resource makes the host pass drop the kernel stub silently)
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias0 + (long)t.batch * sBias), 0, N * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(nt_smem + BIAS_BASE + slot * 1024), 16, (int)((t.b0 + lane * 4) * 4), 0, 0, 0);
+        }
     };
 
     // ---- fragment read offsets (bytes inside an operand tile) ------------------------------------------
@@ -127,6 +153,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     Tile t = decode(vb);
     aim(t);
     stage(0, 0);
+    int slot = 0;
+    stage_bias(t, slot);
     for (;;) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -138,37 +166,66 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         // but the 32 youngest operations are: the stores keep draining under the main loop
         if (stores_after_prefetch) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-            const unsigned char* base = nt_smem + cur * STAGE_BYTES;
+        // (bare s_barrier: __syncthreads() carries a release fence, i.e. a compiler-inserted vmcnt(0) that would wait for the
+        // stores just issued; what the barriers of this kernel order is LDS traffic, waited for explicitly)
+        asm volatile("s_barrier" ::: "memory");
+        if (nk > 0) {
+            // Software-pipelined k loop.  A k-tile is 16 groups of 4 MFMAs (group s: B fragment s & 7 of k-half s >> 3
+            // against the 4 A fragments of that half).  Fragment reads run 4 groups ahead of their MFMAs through a ring
+            // of 8 B registers and two sets of A registers, and they cross the k-tile boundary: at group 12 every read of
+            // the current buffer has been issued, so the wave drains them, the block meets (the next buffer's DMA pieces
+            // are complete, this buffer is free), the k-tile after next is staged into this buffer, and the reads of the
+            // next k-tile's first groups go out under the last 16 MFMAs of this one.
+            bf16x8 fa[2][4], fb[8];
+            auto ldA = [&](const unsigned char* b, int ks, int n) { return *reinterpret_cast<const bf16x8*>(b + offA[ks] + n * 2048); };
+            auto ldB = [&](const unsigned char* b, int ks, int m) { return *reinterpret_cast<const bf16x8*>(b + offB[ks] + m * 2048); };
+            if (nk > 1) stage(1, 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fb[8], fa[4];
+            for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nt_smem, 0, n);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) fa[n] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + n * 2048);
+            for (int m = 0; m < 4; ++m) fb[m] = ldB(nt_smem, 0, m);
+            auto ktile = [&](auto last_tag, int kt) {
+                constexpr bool LAST = decltype(last_tag)::value;
+                const unsigned char* base = nt_smem + (kt & 1) * STAGE_BYTES;
+                const unsigned char* nbase = nt_smem + ((kt & 1) ^ 1) * STAGE_BYTES;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) fb[m] = *reinterpret_cast<const bf16x8*>(base + offB[ks] + m * 2048);
-                __builtin_amdgcn_s_setprio(1);
+                for (int s = 0; s < 16; ++s) {
+                    const int ks = s >> 3, m = s & 7, r = s + 4;
+                    if (r < 16) {
+                        if (r == 8) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
+                            for (int n = 0; n < 4; ++n) fa[1][n] = ldA(base, 1, n);
+                        }
+                        fb[r & 7] = ldB(base, r >> 3, r & 7);
+                    } else if (!LAST) {
+                        if (r == 16) {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            if (kt + 2 < nk) stage(kt & 1, kt + 2);
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nbase, 0, n);
+                        }
+                        fb[r & 7] = ldB(nbase, 0, r & 7);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[n], acc[m][n], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[ks][n], acc[m][n], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            for (int kt = 0; kt + 1 < nk; ++kt) ktile(std::false_type{}, kt);
+            ktile(std::true_type{}, nk - 1);
+            LDS_BARRIER();                                 // every wave is done reading both buffers
         }
         // Both staging buffers are idle now (the trailing barrier retired every read).  The next tile's first k-tile
         // goes into buffer 0 while this tile's epilogue runs out of the LDS above it.
         const Tile cur = t;
         const int nvb = vb + (int)gridDim.x;
         const bool more = nvb < total;
-        if (more) { t = decode(nvb); aim(t); stage(0, 0); }
+        if (more) { t = decode(nvb); aim(t); stage(0, 0); stage_bias(t, slot ^ 1); }
         const int batch = cur.batch, a0 = cur.a0, b0 = cur.b0;
-        const float* bias = bias0 ? bias0 + (long)batch * sBias : nullptr;
+        const float* bias = bias0 ? reinterpret_cast<const float*>(nt_smem + BIAS_BASE + slot * 1024) : nullptr;   // [256] in LDS
+        slot ^= 1;
 
         if (EPI == 1) {
             // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
@@ -181,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             uint32_t* ck = se.cand_key + (size_t)seg * se.capS;
             uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
             if (tid == 0) scnt[0] = 0;
-            __syncthreads();
+            LDS_BARRIER();
             float lbf = key_f32(lb);                          // fast reject in float: !(v < lbf) also lets NaNs through
             if (diag & 32) lbf = INFINITY;                    // (ablation: nothing passes the fast reject)
             if (diag & 16) {                                  // (ablation: no epilogue work at all)
@@ -193,20 +250,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                 vb = nvb;
                 continue;
             }
-            f32x4 bv[8];
+            // (B-fragment index outermost: one bias vector live at a time — the accumulators leave few registers)
+            uint32_t flat_row[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                flat_row[n] = (uint32_t)((long)batch * sC + (long)(a0 + wn * 64 + n * 16 + fr) * ldc);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int col = b0 + wm * 128 + m * 16 + fq * 4;
-                bv[m] = (bias && col < N) ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + wm * 128 + m * 16 + fq * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int row = a0 + wn * 64 + n * 16 + fr;
-                const uint32_t flat_row = (uint32_t)((long)batch * sC + (long)row * ldc);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int col = b0 + wm * 128 + m * 16 + fq * 4;
-                    const f32x4 v = acc[m][n] + bv[m];
+                for (int n = 0; n < 4; ++n) {
+                    const int row = a0 + wn * 64 + n * 16 + fr;
+                    const f32x4 v = acc[m][n] + bv;
                     const bool in = row < M && col < N;
                     const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
                     if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
@@ -216,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t key = f32_key(v[c]);
                             if (key >= lb) {
-                                const uint32_t fi = flat_row + (uint32_t)(col + c);
+                                const uint32_t fi = flat_row[n] + (uint32_t)(col + c);
                                 const uint32_t off = atomicAdd(&scnt[0], 1u);
                                 if (off < (uint32_t)ESTG) { skey[off] = key; sidx[off] = fi; }
                                 else {                           // staging full (pathological tile): straight to the global list
@@ -228,10 +284,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                     }
                 }
             }
-            __syncthreads();
+            LDS_BARRIER();
             const uint32_t staged = min(scnt[0], (uint32_t)ESTG);
             if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
-            __syncthreads();
+            LDS_BARRIER();
             const uint32_t gbase = scnt[1];
             for (uint32_t i = tid; i < staged; i += 512) {
                 const uint32_t pos = gbase + i;
@@ -247,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             const int er = lane >> 5, ec = (lane & 31) * 4;
             const int col = b0 + wm * 128 + ec;
             f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (bias && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+            if (bias) bv = *reinterpret_cast<const f32x4*>(bias + wm * 128 + ec);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -278,6 +334,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
 }
 
+// per-lane DMA offsets are 32-bit byte offsets from the tile's first row (+ the k offset in the scalar offset)
+bool dma_offsets_fit(long lda, long ldb, long K) { return (255 * (lda > ldb ? lda : ldb) + K) * 2 < 0x7fffffffL; }
+
 // persistent grid: one block per CU (a multiple of 8, so that a block keeps its XCD over all its tiles)
 int persistent_grid(long nblk) {
     static int cus = 0;
@@ -298,7 +357,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
     const bool ok = K % TK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
-                    (long)M * N >= 256L * 256L;
+                    (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
     if (!ok) return 1;
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
     const long nblk = (long)tilesA * tilesB * batch;
@@ -338,7 +397,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                                     uint32_t* cand_key, uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !ctl || !cand_key || !cand_idx || capS == 0) return CLT_ERR_SHAPE;
     const bool ok = K % TK == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
-                    aligned16(A) && aligned16(B) && (!bias || aligned16(bias));
+                    aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) && dma_offsets_fit(lda, ldb, K);
     if (!ok) return 1;
     if ((unsigned long long)(batch - 1) * sC + (unsigned long long)(M - 1) * ldc + N > 0xffffffffull) return CLT_ERR_RANGE;
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
