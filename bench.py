@@ -117,7 +117,7 @@ def roofline(timing, mod, args):
         ach = flops / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / BF16_PEAK_TFLOPS, "traffic": None, "launches": len(gv), "avg_launch_us": ms * 1e3 / len(gv),
-                "gemm_ms_per_step": ms / args.steps}
+                "gemm_ms_per_step": ms / len(gv) * timing.get("#gemm", len(gv)) / args.steps}
     col_start = lists.col_start.cpu().long()
     bf16 = args.precision.startswith("bf16")
     nbytes = ms = 0.0
