@@ -98,7 +98,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     int vB[4], vA[4];
     __amdgpu_buffer_rsrc_t rB, rA;
     long brow0 = 0;
-    auto rsrc = [](const uint16_t* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p), 0, -1, 0x00020000); };
+    // (extent 2 GiB: per-lane offsets stay below it, and an offset with bit 31 set reads as zero — the k tail below)
+    auto rsrc = [](const uint16_t* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p), 0, (int)0x80000000u, 0x00020000); };
+    // K need only be a multiple of 8: in the last k-tile the lanes whose 16-byte chunk starts at k >= K aim out of the
+    // descriptor's range, so zeros land in LDS (a lane's logical chunk is the same for its four rows of a piece)
+    const int nk = (diag & 2) ? 0 : (K + TK - 1) / TK;
+    const int my_chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);
+    const int tail_oob = (K % TK != 0 && my_chunk * 8 >= K % TK) ? (int)0x80000000u : 0;
     auto aim = [&](const Tile& t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -117,14 +123,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     auto stage = [&](int buf, int kt) {
         unsigned char* base = nt_smem + buf * STAGE_BYTES;
         int sob = kt * (TK * 2);
+        const int oob = kt == nk - 1 ? tail_oob : 0;
         __amdgpu_buffer_rsrc_t rb = rB;
         if (EPI == 0 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i], sob, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i], kt * (TK * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i] | oob, kt * (TK * 2), 0, 0);
     };
 
     // The tile's bias slice rides along as a ninth DMA piece of wave 0 (columns past N read as zero through the
@@ -146,7 +153,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         offB[ks] = (wm * 128 + fr) * 128 + phys * 16;
         offA[ks] = OP_BYTES + (wn * 64 + fr) * 128 + phys * 16;
     }
-    const int nk = (diag & 2) ? 0 : K / TK;
 
     bool stores_after_prefetch = false;
     int vb = blockIdx.x;
@@ -355,7 +361,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
                               hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
-    const bool ok = K % TK == 0 && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
+    const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
     if (!ok) return 1;
@@ -396,7 +402,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                                     long sA, long sB, long sC, const float* bias, long sBias, const uint32_t* ctl,
                                     uint32_t* cand_key, uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !ctl || !cand_key || !cand_idx || capS == 0) return CLT_ERR_SHAPE;
-    const bool ok = K % TK == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
+    const bool ok = K % 8 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
                     aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) && dma_offsets_fit(lda, ldb, K);
     if (!ok) return 1;
     if ((unsigned long long)(batch - 1) * sC + (unsigned long long)(M - 1) * ldc + N > 0xffffffffull) return CLT_ERR_RANGE;

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
 // so no contention on the handful of exponent bins that nearly all pre-activations share.
 // ------------------------------------------------------------------------------------------------
 constexpr int RT = 1024, RW = RT / 64, RCAP = 2048;
+// block barrier that orders LDS traffic only (global loads / stores / DMA pieces stay in flight across it)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf_raw[];   // the next row, filled by LDS-DMA
 
 // m-th largest of the 64 values one wave holds (one per lane): binary search on the key bits, two bits per step, counted
@@ -126,17 +128,20 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     __shared__ int32_t oidx[1024];
     __shared__ float oval[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w);      // (scalar copy for the DMA's LDS base)
     // Persistent block: rows blockIdx.x, + gridDim.x, ...  While a row is processed out of registers the next one streams
     // into LDS by DMA (global_load_lds, 16 bytes per lane, no registers), so the HBM read overlaps the selection work.
     float* rowbuf = reinterpret_cast<float*>(rowbuf_raw);
+    // (MUBUF form of the DMA and LDS-only barriers: __syncthreads() carries a release fence, i.e. a vmcnt(0) that would wait
+    // for the row just requested, and FLAT-encoded global_load_lds in flight turns every LDS wait into a full drain)
     auto prefetch = [&](long r) {
-        const float* src = x + r * F;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + r * F), 0, F * 4, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NPT / 4; ++j) {
             const int i0 = (j * RT + tid) * 4;
             if (i0 < F)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0),
-                                                 (__attribute__((address_space(3))) void*)(rowbuf_raw + (size_t)(j * RT + w * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rowbuf_raw + (size_t)(j * RT + wu * 64) * 16),
+                                                         16, i0 * 4, 0, 0, 0);
         }
     };
     prefetch(blockIdx.x);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     if (tid < 64) step_cnt[tid >> 2][tid & 3] = 0;
     if (tid == 0) cursor = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                        // this row has landed in LDS (every wave's DMA pieces)
+    LDS_BARRIER();                                        // this row has landed in LDS (every wave's DMA pieces)
     // element e of this thread has index ((e / 4) * RT + tid) * 4 + e % 4; keys of positions >= F are 0 (below every real key)
     uint32_t key[NPT];
     uint32_t tmax = 0;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const uint32_t kk = in ? f32_key(a[c]) : 0u; key[j * 4 + c] = kk; tmax = max(tmax, kk); }
     }
-    __syncthreads();                                        // every thread holds its keys: the buffer may be refilled
+    LDS_BARRIER();                                        // every thread holds its keys: the buffer may be refilled
     if (row + gridDim.x < nrows) prefetch(row + gridDim.x);
     // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
     // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
         if (lane == 0) wlb[w] = mth;
     }
     // candidates >= LB, compacted into LDS
-    __syncthreads();
+    LDS_BARRIER();
     if (k <= RT) {
         LB = wlb[0];
 #pragma unroll
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) wtot[w] = inc;
-    __syncthreads();
+    LDS_BARRIER();
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < RW; ++i) { const uint32_t s = wtot[i]; if (i < w) base += s; total += s; }
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
         uint32_t pos = base + inc - cnt;
 #pragma unroll
         for (int e = 0; e < NPT; ++e) if (key[e] >= LB) ckey[pos++] = key[e];
-        __syncthreads();
+        LDS_BARRIER();
         if (total <= 64u) {                                 // the usual case for k << F: one wave finishes the search alone
             if (w == 0) {
                 const uint32_t ckl = (uint32_t)lane < total ? ckey[lane] : 0u;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
                     c[2] += (uint32_t)__popcll(__ballot(ck[q] >= (t | (3u << b))));
                 }
                 if (lane < 3) { const uint32_t mine = lane == 0 ? c[0] : (lane == 1 ? c[1] : c[2]); if (mine) atomicAdd(&step_cnt[st][lane], mine); }
-                __syncthreads();
+                LDS_BARRIER();
                 const uint32_t s1 = step_cnt[st][0], s2 = step_cnt[st][1], s3 = step_cnt[st][2];
                 if (s3 >= (uint32_t)k) t |= 3u << b;
                 else if (s2 >= (uint32_t)k) t |= 2u << b;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             }
             if (tid == 0) Tsh = t;
         }
-        __syncthreads();
+        LDS_BARRIER();
         T = Tsh;
     } else {                                               // (k > 1024, or a row of mostly equal values): search all the keys,
         T = 0;                                             // one bit and one threshold per step
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
             if (lane == 0) red[parity][w] = make_uint2(c, 0u);
-            __syncthreads();
+            LDS_BARRIER();
             uint32_t sum = 0;
 #pragma unroll
             for (int i = 0; i < RW; ++i) sum += red[parity][i].x;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { cgt += __shfl_xor(cgt, o, 64); ceq += __shfl_xor(ceq, o, 64); }
         if (lane == 0) red[parity][w] = make_uint2(cgt, ceq);
-        __syncthreads();
+        LDS_BARRIER();
 #pragma unroll
         for (int i = 0; i < RW; ++i) { const uint2 r = red[parity][i]; ngt += r.x; neq += r.y; }
         parity ^= 1;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
             if (lane == 63) red[parity][w] = make_uint2(sc, 0u);
-            __syncthreads();
+            LDS_BARRIER();
             uint32_t pb = 0, pt = 0;
 #pragma unroll
             for (int i = 0; i < RW; ++i) { const uint32_t s2 = red[parity][i].x; if (i < w) pb += s2; pt += s2; }
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
         if (fr && i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
     }
     if (idx_out) {                          // order the <= k positive entries by feature index (rank sort)
-        __syncthreads();
+        LDS_BARRIER();
         const int n = (int)cursor;
         if (row_cnt && tid == 0) row_cnt[row] = n;
         for (int e = tid; e < k; e += RT) {
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             } else { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
         }
     }
-    __syncthreads();                                        // the per-row LDS state is reset at the top of the next row
+    LDS_BARRIER();                                          // the per-row LDS state is reset at the top of the next row
     }
 }
 

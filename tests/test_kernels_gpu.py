@@ -467,10 +467,12 @@ def test_select_lists_ties_fallback_and_edges(ops):
             ops.select_lists(x, 6, mode)
 
 
-@pytest.mark.parametrize("Bn,L,d,F", [(300, 2, 128, 520), (256, 1, 64, 256), (1000, 3, 192, 1028), (513, 2, 768, 260)])
+@pytest.mark.parametrize("Bn,L,d,F", [(300, 2, 128, 520), (256, 1, 64, 256), (1000, 3, 192, 1028), (513, 2, 768, 260),
+                                      (300, 2, 72, 520), (260, 1, 200, 300), (256, 2, 104, 256), (270, 1, 8, 256)])
 def test_gemm_nt_fast_path(ops, Bn, L, d, F):
-    """The glds / 16x16x32 NT kernel (K % 64 == 0, M*N >= 256^2): encoder forward with bias, edge tiles in both
-    directions, batched; plus accumulate and the A = I asymmetric-B layout check."""
+    """The LDS-DMA / 16x16x32 NT kernel (K % 8 == 0 — a k tail shorter than the 64-wide k-tile is zero-filled by
+    out-of-range DMA offsets —, M*N >= 256^2): encoder forward with bias, edge tiles in both directions, batched; plus
+    accumulate and the A = I asymmetric-B layout check."""
     bf = torch.bfloat16
     xs, Wt = _rand(Bn, L, d, seed=1).to(bf), _rand(L, F, d, seed=2, scale=d ** -0.5).to(bf)
     b = _rand(L, F, seed=3, scale=0.1)
