@@ -325,7 +325,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     feat = S = pre = fused_ops = dpreT = None
     batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
     if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
-            and getattr(nl, "_kth", None) is not None and d % 64 == 0 and F % 4 == 0):
+            and getattr(nl, "_kth", None) is not None and d % 8 == 0 and F % 4 == 0):
         mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
                                           nl.e, shard)

@@ -281,7 +281,7 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
     # (target, source) pairs in persistent grouped launches, one fp32 slab per pair; consecutive target layers share a
     # launch as long as their slabs fit GROUPED_SLAB_BYTES (G32: all 78 pairs, 1 GB, one launch)
-    if F % 64 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
+    if F % 8 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
         slab_b = 4 * Bn * d
         l0, ok = 0, True
         while l0 < L and ok:
@@ -337,7 +337,7 @@ def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Ten
     L, F, Bn = fT.shape
     d = gT.shape[1]
     _chk(fT, torch.bfloat16); _chk(gT, torch.bfloat16)
-    if Bn % 64 or d % 4 or F * d < 256 * 256:
+    if Bn % 8 or d % 4 or F * d < 256 * 256:
         return False
     rec = []
     for l in range(L):
