@@ -366,6 +366,54 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const float* __r
     ft_write_transposed(tile, featT, c0, r0, rows, n);
 }
 
+// Per-step preparation of a dense-regime decoder weight tensor W [nb][rows][n] fp32 in ONE read: the bf16 copy (feature-
+// gradient GEMM operand), the bf16 transposed copy [nb][n][rows] (forward GEMM operand: contraction index contiguous) and the
+// squared row norms sq[b*rows + r] (+)= sum_j W^2 (dec_norms of the sparsity penalty, clt_lightning.py:438-448) — three
+// separate passes over 7.85 GB of decoder weights otherwise.  grid (ceil(rows/64), nb); a block walks the column tiles of
+// its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
+                                                          uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate) {
+    __shared__ uint16_t tile[FT_R][FT_PITCH];
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * FT_R;
+    const long boff = (long)blockIdx.y * rows * n;
+    W += boff;
+    if (op) op += boff;
+    if (opT) opT += boff;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (long c0 = 0; c0 < n; c0 += FT_C) {
+        const long col = c0 + 4 * tx;
+        const bool cin = col < n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = w + 4 * i, row = r0 + r;
+            const bool in = cin && row < rows;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (in) v = *reinterpret_cast<const float4*>(W + (long)row * n + col);
+            acc[i] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            const uint16_t h[4] = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+            if (in && op)
+                *reinterpret_cast<uint2*>(op + (long)row * n + col) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            ft_store_row(tile, r, tx, h);
+        }
+        if (opT) {
+            __syncthreads();
+            ft_write_transposed(tile, opT, c0, r0, rows, n);
+            __syncthreads();
+        }
+    }
+    if (sq) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float s = wave_sum(acc[i]);
+            const int row = r0 + w + 4 * i;
+            if (tx == 0 && row < rows) { float* q = sq + (long)blockIdx.y * rows + row; *q = accumulate ? *q + s : s; }
+        }
+    }
+}
+
 // grid (ceil(n/256), ceil(rows/256)): a block walks 4 row tiles of its 256 columns, keeping the column partial sums in
 // registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
 __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const float* __restrict__ x, const float* __restrict__ theta,
@@ -719,6 +767,14 @@ int clt_cast_bf16(const float* in, uint16_t* out, long n, void* st) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), in, out, n);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
+int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, uint16_t* opT, float* sq, int accumulate, void* st) {
+    if (nb <= 0 || rows <= 0 || n <= 0 || !W) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(W) || (op && !aligned16(op)) || (opT && !aligned16(opT))) return CLT_ERR_ALIGN;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
+    CLT_LAUNCH_CHECK();
+    return CLT_OK;
+}
+
 int clt_cast_transpose_bf16(const float* in, long ldi, uint16_t* out, long ldo, int rows, int cols, int batch, long s_in,
                             long s_out, void* st) {
     if (rows <= 0 || cols <= 0 || batch <= 0 || ldi < cols || ldo < rows) return CLT_ERR_SHAPE;

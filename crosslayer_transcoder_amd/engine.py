@@ -93,6 +93,8 @@ COMPACT_AUX_MAX_SHARE = 0.5
 #: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
 FUSE_DENSE_JUMPRELU = True
+#: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
+FUSE_WEIGHT_PREP = True
 
 
 def _encoder_operand(enc):
@@ -137,10 +139,26 @@ class _Decoder:
         self.L = dec.n_layers
         self.W32 = dec.weights()
         self.bf16 = get_precision() == "bf16"
-        self._Wop = self._WT = None
+        self._Wop = self._WT = self._sq = None
+
+    def _prep(self):
+        """bf16 dense regime: bf16 copy, transposed bf16 copy and squared row norms of every decoder matrix from ONE
+        read of it (`clt_weight_prep_bf16`) instead of three passes over the decoder weights."""
+        if self._Wop is not None or self._WT is not None or not (self.bf16 and FUSE_WEIGHT_PREP):
+            return
+        F = self.dec.d_features
+        sq = torch.zeros(self.L * F, dtype=torch.float32, device=self.W32[0].device)
+        Wop, WT = [], []
+        for w in self.W32:                      # ascending l: the reference's accumulation order (:440-444)
+            r = ops.weight_prep_bf16(w, sq, True) if w.is_contiguous() else None
+            if r is None:
+                return
+            Wop.append(r[0]); WT.append(r[1])
+        self._Wop, self._WT, self._sq = Wop, WT, sq
 
     @property
     def Wop(self):
+        self._prep()
         if self._Wop is None:
             self._Wop = [_op(w) for w in self.W32]
         return self._Wop
@@ -148,6 +166,7 @@ class _Decoder:
     @property
     def WT(self):
         """bf16 [n, d, F] transposed copies of the decoder matrices (forward B operand, k = feature contiguous)."""
+        self._prep()
         if self._WT is None:
             self._WT = [ops.cast_transpose_bf16(w.contiguous()) for w in self.W32]
         return self._WT
@@ -212,6 +231,8 @@ class _Decoder:
             grads["decoder.W"] = ops.plt_decoder_wgrad(feat, g, grads.get("decoder.W"), accumulate="decoder.W" in grads)
 
     def sqnorms(self):
+        if self._sq is not None:
+            return self._sq
         F = self.dec.d_features
         sq = torch.zeros(self.L * F, dtype=torch.float32, device=self.W32[0].device)
         for w in self.W32:                      # ascending l: the reference's accumulation order (:440-444)

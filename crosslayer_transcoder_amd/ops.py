@@ -372,6 +372,20 @@ def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def weight_prep_bf16(w: torch.Tensor, sq: Optional[torch.Tensor] = None, accumulate: bool = True):
+    """w: fp32 [nb, rows, n] -> (bf16 copy, bf16 [nb, n, rows] transposed copy) in one read; sq (fp32 [>= nb*rows]) gets
+    the squared row norms added (or stored).  None when the shape does not qualify (rows % 8, n % 4)."""
+    _chk(w)
+    nb, rows, n = w.shape
+    if rows % 8 or n % 4:
+        return None
+    op = torch.empty(nb, rows, n, dtype=torch.bfloat16, device=w.device)
+    opT = torch.empty(nb, n, rows, dtype=torch.bfloat16, device=w.device)
+    call("clt_weight_prep_bf16", w.data_ptr(), nb, rows, n, op.data_ptr(), opT.data_ptr(),
+         _chk(sq).data_ptr() if sq is not None else None, int(accumulate), _stream())
+    return op, opT
+
+
 # ----------------------------------------------------------------------------------------------- K3
 def relu_fwd(x):
     out = torch.empty_like(_chk(x))

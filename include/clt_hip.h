@@ -71,6 +71,12 @@ int clt_sum_slabs_f32(const float* slabs, int nslab, long slab_stride, int rows,
 int clt_cast_bf16(const float* in, uint16_t* out, long n, void* stream);
 int clt_cast_transpose_bf16(const float* in, long ld_in, uint16_t* out, long ld_out, int rows, int cols,
                             int batch, long s_in, long s_out, void* stream);
+/* One read of a dense-regime decoder weight tensor W [nb][rows][n] (rows % 8 == 0, n % 4 == 0, 16-byte aligned) for all
+ * three things the step derives from it: op = bf16 copy, opT = bf16 [nb][n][rows] transposed copy (autocast's casts +
+ * the transposes of the bmm operands, clt.py:334-343 under bf16-mixed), sq[b*rows + r] (+)= squared row norms (dec_norms,
+ * clt_lightning.py:438-448).  op / opT / sq may each be NULL. */
+int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, uint16_t* opT, float* sq, int accumulate,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  ReLU / JumpReLU — model/jumprelu.py:17-22, :31-48

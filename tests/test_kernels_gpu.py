@@ -564,3 +564,21 @@ def test_clt_decoder_fwd_grouped_launches(ops, monkeypatch):
             want[:, l] += fd[:, lp] @ WTs[l][lp].double().cpu().T
         want[:, l] += bias[l].double().cpu()
     assert torch.allclose(one.double().cpu(), want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("nb,rows,n", [(3, 200, 768), (1, 64, 256), (2, 1000, 108)])
+def test_weight_prep_one_pass(ops, nb, rows, n):
+    """clt_weight_prep_bf16 == cast_bf16 + cast_transpose_bf16 (bit-exact) + row_sqnorm (accumulating) of the same tensor."""
+    w = _rand(nb, rows, n, seed=31).to(DEV)
+    sq0 = torch.rand(nb * rows + 5, generator=torch.Generator().manual_seed(3)).to(DEV)
+    sq = sq0.clone()
+    op, opT = ops.weight_prep_bf16(w, sq, True)
+    assert torch.equal(op, ops.cast_bf16(w)) and torch.equal(opT, ops.cast_transpose_bf16(w))
+    ref = sq0.clone()
+    ref[: nb * rows] += (w.double() ** 2).sum(-1).reshape(-1).float()
+    assert torch.allclose(sq, ref, rtol=1e-6, atol=0)
+    assert torch.equal(sq[nb * rows:], sq0[nb * rows:])
+    sq2 = torch.full_like(sq0, 7.0)
+    ops.weight_prep_bf16(w, sq2, False)
+    assert torch.allclose(sq2[: nb * rows], (w.double() ** 2).sum(-1).reshape(-1).float(), rtol=1e-6, atol=0)
+    assert ops.weight_prep_bf16(_rand(1, 12, 768, seed=1).to(DEV)) is None          # rows % 8 != 0: caller falls back
