@@ -118,10 +118,11 @@ template <int NPT>
 __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
                                                            int32_t* __restrict__ idx_out, float* __restrict__ val_out,
                                                            const uint8_t* __restrict__ col_mask, int L,
-                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows) {
+                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows, int diag) {
     __shared__ uint2 red[2][RW];
     __shared__ uint32_t ckey[RCAP];
-    __shared__ uint32_t wtot[RW];
+    __shared__ int32_t cidx[RCAP];                         // feature index of each candidate
+    __shared__ uint32_t ccur;                              // candidate count (compaction cursor)
     __shared__ uint32_t wlb[RW];
     __shared__ uint32_t step_cnt[16][4];                   // block-wide search: per step the counts of 3 thresholds
     __shared__ uint32_t cursor, Tsh, cnt_sh[2];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
     int parity = 0;
     if (tid < 64) step_cnt[tid >> 2][tid & 3] = 0;
-    if (tid == 0) cursor = 0;
+    if (tid == 0) { cursor = 0; ccur = 0; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LDS_BARRIER();                                        // this row has landed in LDS (every wave's DMA pieces)
     // element e of this thread has index ((e / 4) * RT + tid) * 4 + e % 4; keys of positions >= F are 0 (below every real key)
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     }
     LDS_BARRIER();                                        // every thread holds its keys: the buffer may be refilled
     if (row + gridDim.x < nrows) prefetch(row + gridDim.x);
+    if (diag & 1) { if (tmax == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }     // (ablation: streaming + key extraction only)
     // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
     // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
     uint32_t LB = 0;
@@ -185,23 +187,61 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
         for (int i = 1; i < RW; ++i) LB = min(LB, wlb[i]);
     }
-    uint32_t cnt = 0;
+    if (diag & 2) { if (LB == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }        // (ablation: + lower bound)
+    // (key, index) pairs of the candidates go to LDS in arrival order: per register slot one ballot — nearly always
+    // empty, k << F — and one LDS atomic per wave that has any; the exact search does not depend on the order
 #pragma unroll
-    for (int e = 0; e < NPT; ++e) cnt += key[e] >= LB ? 1u : 0u;
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) wtot[w] = inc;
+    for (int e = 0; e < NPT; ++e) {
+        const bool c = key[e] >= LB;
+        const unsigned long long m = __ballot(c);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ccur, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (c) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < (uint32_t)RCAP) { ckey[pos] = key[e]; cidx[pos] = ((e >> 2) * RT + tid) * 4 + (e & 3); }
+        }
+    }
     LDS_BARRIER();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < RW; ++i) { const uint32_t s = wtot[i]; if (i < w) base += s; total += s; }
+    const uint32_t total = ccur;
     uint32_t T;
-    if (total <= (uint32_t)RCAP) {
-        uint32_t pos = base + inc - cnt;
-#pragma unroll
-        for (int e = 0; e < NPT; ++e) if (key[e] >= LB) ckey[pos++] = key[e];
+    // List output (no dense row): the row is finished from the candidate pairs alone.  Every candidate ranks itself in
+    // the order (key descending, feature index ascending) — one thread per candidate, broadcast LDS reads of the others —
+    // and the first k of that order are exactly the selection with the lowest-index tie rule; no search for the k-th key.
+    if (total <= (uint32_t)RCAP && !feat && idx_out) {
+        for (uint32_t c = tid; c < total; c += RT) {
+            const uint32_t mkey = ckey[c];
+            const int mi = cidx[c];
+            uint32_t rank = 0;
+#pragma unroll 4
+            for (uint32_t j = 0; j < total; ++j) {
+                const uint32_t kj = ckey[j];
+                const int ij = cidx[j];
+                rank += (kj > mkey || (kj == mkey && ij < mi)) ? 1u : 0u;
+            }
+            const float v = key_f32(mkey);
+            if (rank < (uint32_t)k && v > 0.0f) {
+                const uint32_t sl = atomicAdd(&cursor, 1u);
+                oidx[sl] = mi; oval[sl] = v;
+                if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + mi], 1u);
+            }
+        }
         LDS_BARRIER();
+        const int n = (int)cursor;
+        if (row_cnt && tid == 0) row_cnt[row] = n;
+        for (int e = tid; e < k; e += RT) {                 // order the <= k positive entries by feature index (rank sort)
+            if (e < n) {
+                const int me = oidx[e];
+                int pos = 0;
+                for (int q = 0; q < n; ++q) pos += oidx[q] < me;
+                idx_out[row * k + pos] = me; val_out[row * k + pos] = oval[e];
+            } else { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
+        }
+        LDS_BARRIER();                                      // the per-row LDS state is reset at the top of the next row
+        continue;
+    }
+    if (total <= (uint32_t)RCAP) {
         if (total <= 64u) {                                 // the usual case for k << F: one wave finishes the search alone
             if (w == 0) {
                 const uint32_t ckl = (uint32_t)lane < total ? ckey[lane] : 0u;
@@ -250,6 +290,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             if (sum >= (uint32_t)k) T = cand;
         }
     }
+    if (diag & 4) { if (T == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }         // (ablation: + exact k-th value)
     // counts above / at T (the single-wave search already has them)
     uint32_t ngt = 0, neq = 0;
     if (total <= 64u) { ngt = cnt_sh[0]; neq = cnt_sh[1]; }
@@ -460,7 +501,7 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         const int grid = rows < cus ? rows : cus;
         const size_t dyn = (size_t)((F + 4095) / 4096) * 4096 * 4;           // whole 16 KB DMA rounds
 #define TKR(NPT_) do { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_reg_kernel<NPT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return CLT_ERR_LAUNCH; \
-        hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows); } while (0)
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows, getenv("CLT_TOPK_DIAG") ? atoi(getenv("CLT_TOPK_DIAG")) : 0); } while (0)
         const int per = (F + RT - 1) / RT;
         if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 16) TKR(16); else TKR(32);
 #undef TKR
