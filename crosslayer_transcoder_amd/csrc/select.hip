@@ -94,7 +94,7 @@ __global__ __launch_bounds__(TPB) void topk_rows_kernel(const float* __restrict_
 // largest (k <= 1024), then over the few candidates >= that bound (compacted into LDS).  No LDS atomics on the data,
 // so no contention on the handful of exponent bins that nearly all pre-activations share.
 // ------------------------------------------------------------------------------------------------
-constexpr int RT = 1024, RW = RT / 64, RCAP = 2048;
+constexpr int RT = 1024, RW = RT / 64, RCAP = 2048, RANK_TAIL_MAX = 256;
 // block barrier that orders LDS traffic only (global loads / stores / DMA pieces stay in flight across it)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf_raw[];   // the next row, filled by LDS-DMA
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     // List output (no dense row): the row is finished from the candidate pairs alone.  Every candidate ranks itself in
     // the order (key descending, feature index ascending) — one thread per candidate, broadcast LDS reads of the others —
     // and the first k of that order are exactly the selection with the lowest-index tie rule; no search for the k-th key.
-    if (total <= (uint32_t)RCAP && !feat && idx_out) {
+    // Quadratic in the candidates, so only for the usual short lists (k << F); longer ones take the search below.
+    if (total <= (uint32_t)RANK_TAIL_MAX && !feat && idx_out) {
         for (uint32_t c = tid; c < total; c += RT) {
             const uint32_t mkey = ckey[c];
             const int mi = cidx[c];
@@ -310,11 +311,15 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     const bool rank_ties = (neq != krem) && (key_f32(T) > 0.0f);
     uint32_t running = 0;                                   // ties before this group of 4 * RT indices
     float* fr = feat ? feat + row * F : nullptr;
+    // long lists (k > 64): the entries get their places in feature order from an ordered block scan per group of 4 * RT
+    // indices (index order = group, thread, element) instead of the quadratic rank sort below
+    const bool ordered = idx_out && k > 64;
+    uint32_t run_out = 0;
 #pragma unroll
     for (int j = 0; j < NPT / 4; ++j) {
         const int i0 = (j * RT + tid) * 4;
         // list output only (no dense row to write): a wave whose 256 keys of this group are all below T has nothing to do
-        if (!fr && !rank_ties &&
+        if (!fr && !rank_ties && !ordered &&
             !__any(key[j * 4] >= T || key[j * 4 + 1] >= T || key[j * 4 + 2] >= T || key[j * 4 + 3] >= T)) continue;
         uint32_t before = 0;                                // ties with a lower index inside this group
         if (rank_ties) {                                    // (block-uniform branch) ordered scan: thread order, then c
@@ -341,15 +346,40 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             if (kk == T) { sel = rank_ties ? before < krem : true; ++before; }
             const float v = key_f32(kk);
             o4[c] = (sel && v > 0.0f && i0 + c < F) ? v : 0.0f;
-            if (idx_out && o4[c] > 0.0f) {
+            if (idx_out && !ordered && o4[c] > 0.0f) {
                 const uint32_t sl = atomicAdd(&cursor, 1u);
                 oidx[sl] = i0 + c; oval[sl] = o4[c];
                 if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + i0 + c], 1u);
             }
         }
+        if (ordered) {                                      // (block-uniform branch)
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += o4[c] > 0.0f ? 1u : 0u;
+            uint32_t sc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(sc, o, 64); if (lane >= o) sc += t; }
+            if (lane == 63) red[parity][w] = make_uint2(sc, 0u);
+            LDS_BARRIER();
+            uint32_t pb = 0, pt = 0;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) { const uint32_t s2 = red[parity][i].x; if (i < w) pb += s2; pt += s2; }
+            parity ^= 1;
+            uint32_t p = run_out + pb + sc - mine;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (o4[c] > 0.0f) {
+                    idx_out[row * k + p] = i0 + c; val_out[row * k + p] = o4[c]; ++p;
+                    if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + i0 + c], 1u);
+                }
+            run_out += pt;
+        }
         if (fr && i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
     }
-    if (idx_out) {                          // order the <= k positive entries by feature index (rank sort)
+    if (ordered) {
+        if (row_cnt && tid == 0) row_cnt[row] = run_out;
+        for (int e = (int)run_out + tid; e < k; e += RT) { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
+    } else if (idx_out) {                   // order the <= k positive entries by feature index (rank sort)
         LDS_BARRIER();
         const int n = (int)cursor;
         if (row_cnt && tid == 0) row_cnt[row] = n;

@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from crosslayer_transcoder_amd._lib import lib
-rows, F, k = 4096 * 12, int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 16
+rows, F, k = 4096 * 12, int(sys.argv[1]) if len(sys.argv) > 1 else 32768, int(sys.argv[2]) if len(sys.argv) > 2 else 16
 x = torch.randn(rows, F, device="cuda")
 idx = torch.empty(rows, k, dtype=torch.int32, device="cuda"); val = torch.empty(rows, k, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
