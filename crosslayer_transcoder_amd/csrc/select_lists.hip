@@ -26,7 +26,9 @@ constexpr int STG = 512;                      // per-wave candidate staging entr
 
 struct SelCtl { uint32_t lb, cand_cnt, pad0, pad1; };
 struct Shard { int world, rank; uint32_t f_off, F_global; };   // feature-axis sharding: this rank owns columns [f_off, f_off + F)
-struct Head { int32_t gate; uint32_t sel_cnt, long_rows, long_cols; uint32_t pad[60]; };   // 256 B, zeroed per call
+struct Head { int32_t gate; uint32_t sel_cnt, long_rows, long_cols, above_cnt; uint32_t pad[59]; };   // 256 B, zeroed per call
+// gate bits: 1 = the candidate lists / tie lists did not hold what the exact selection needs (rerun exhaustively),
+//            2 = some shard would select more entries than its list capacity (rerun with full capacity)
 
 __device__ __forceinline__ long lseg_row(int q, int s, int S, int L) { return S == 1 ? (long)q : (long)q * L + s; }
 
@@ -194,29 +196,45 @@ __device__ __forceinline__ uint32_t global_index(uint32_t idx, int F, const Shar
     return row * sd.F_global + sd.f_off + f;
 }
 
-// candidates equal to the k-th value, when only some of them are selected (lowest flat index first)
+// candidates equal to the k-th value, when only some of them are selected (lowest flat index first); and the number of
+// entries this shard will certainly emit (positive candidates above the k-th value, all ties when none are ranked)
 __global__ __launch_bounds__(TPB) void ties_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
                                                    const SelCtl* __restrict__ ctl, const SegState* __restrict__ state, int S, int F,
-                                                   Shard sd, uint32_t* __restrict__ tie_region, const Head* __restrict__ head) {
+                                                   Shard sd, uint32_t* __restrict__ tie_region, Head* __restrict__ head) {
     if (head->gate) return;
+    __shared__ uint32_t sh[8];
     const int s = blockIdx.y;
     const SegState st = state[s];
-    if (!need_rank(st)) return;
+    const bool nr = need_rank(st);
     uint32_t* blk = tie_region + sd.rank * tie_block_words(S);
     const uint32_t n = ctl[s].cand_cnt;
+    uint32_t cnt = 0;
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-        if (cand_key[(size_t)s * capS + i] == st.prefix) {
+        const uint32_t key = cand_key[(size_t)s * capS + i];
+        if (key <= 0x80000000u) continue;               // value <= 0: never emitted
+        if (key > st.prefix || (!nr && key == st.prefix)) ++cnt;
+        else if (nr && key == st.prefix) {
             const uint32_t pos = atomicAdd(&blk[s], 1u);
             if (pos < TIECAP) blk[S + 1 + (size_t)s * TIECAP + pos] = global_index(cand_idx[(size_t)s * capS + i], F, sd);
         }
     }
+    uint32_t tot;
+    block_excl_scan(cnt, sh, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&head->above_cnt, tot);
 }
-// own tie block: overflow -> gate; publish the local gate in the block so that the gather carries it
-__global__ void check_ties_kernel(int S, Shard sd, uint32_t* __restrict__ tie_region, Head* __restrict__ head) {
+// own tie block: overflow -> gate; more entries than the lists hold -> gate bit 2; publish the local gate in the block so
+// that the gather carries it
+__global__ void check_ties_kernel(int S, Shard sd, uint32_t* __restrict__ tie_region, Head* __restrict__ head,
+                                  const SegState* __restrict__ state, uint32_t capsel) {
     uint32_t* blk = tie_region + sd.rank * tie_block_words(S);
-    for (int s = threadIdx.x; s < S; s += blockDim.x) if (blk[s] > TIECAP) head->gate = 1;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) if (blk[s] > TIECAP) atomicOr(&head->gate, 1);
     __syncthreads();
-    if (threadIdx.x == 0) blk[S] = (uint32_t)head->gate;
+    if (threadIdx.x == 0) {
+        unsigned long long bound = head->above_cnt;
+        for (int s = 0; s < S; ++s) if (need_rank(state[s])) bound += min(blk[s], state[s].krem);
+        if (bound > capsel) head->gate |= 2;
+        blk[S] = (uint32_t)head->gate;
+    }
 }
 // after the gather: gate = OR over shards
 __global__ void merge_gate_kernel(int S, int world, const uint32_t* __restrict__ tie_region, Head* __restrict__ head) {
@@ -465,7 +483,9 @@ int run_stages(const SelArgs& a, int lo, int hi) {
         } else if (stage == 4) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
-            hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head);
+            const unsigned long long kall4 = (unsigned long long)p.Kseg * p.S;
+            hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head, state,
+                               a.cap < kall4 ? a.cap : (uint32_t)kall4);
         } else if (stage == 5 || stage == 6) {
             // split (flags & 4, the ext entry point): stage 5 = merge the gate and publish it, stage 6 = emit + lists —
             // the host can read the outcome flag while stage 6 still runs

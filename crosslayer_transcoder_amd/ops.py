@@ -726,13 +726,6 @@ def select_lists(x: torch.Tensor, k: int, mode: int, threshold: Optional[torch.T
     return s
 
 
-def _any_rank(shard, flag: torch.Tensor) -> bool:
-    """True on every rank when `flag` (int32 [1]) is non-zero on any rank (one small all-reduce + host read)."""
-    t = flag.clone()
-    shard.all_reduce_sum(t)
-    return int(t) != 0
-
-
 def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: Optional[torch.Tensor] = None, e: float = 0.0,
                          col_mask: Optional[torch.Tensor] = None, cap: Optional[int] = None) -> SparseLists:
     """Feature-sharded BatchTopK / PerLayerBatchTopK selection (x = this rank's [B, L, F_local] pre-activations,
@@ -780,14 +773,15 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
             stages(0, 5)
             break
         run_sharded_selection(stages, shard, S, exchange)
-        if int(fb) != 0:                           # host read: did every rank have enough candidates?
+        outcome = int(fb)                          # host read of the gate every rank agrees on (it rides in the tie gather)
+        if outcome & 2 and cap < kglob:
+            # a shard holding far more than its share of the selection would overflow its list capacity: redo the
+            # selection with room for the whole selection on every shard
+            attempts.insert(0, (exhaustive, kglob))
+            continue
+        if outcome != 0:                           # not every rank had enough candidates (or too many exact ties)
             if exhaustive:
                 raise NotImplementedError("BatchTopK under feature sharding: more than 4096 values tied at the threshold on one shard")
-            continue
-        # a shard that holds far more than its share of the selection overflows its list capacity: every rank learns it
-        # (the schedule is collective) and the selection is redone with room for the whole selection
-        if cap < kglob and _any_rank(shard, s.overflow):
-            attempts.insert(0, (exhaustive, kglob))
             continue
         break
     s.used_fallback = torch.full((1,), exhaustive, dtype=torch.int32, device=x.device)
@@ -849,8 +843,6 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
         host.copy_(fb, non_blocking=True)
     side.synchronize()
     if int(host) != 0:
-        return None, None
-    if shard is not None and s.cap < kglob and _any_rank(shard, s.overflow):     # list capacity of a shard exceeded: ordinary path
         return None, None
     T = i32(off[6], 4 * S).view(S, 4)[:, 0].clone()
     s.used_fallback = fb
