@@ -5,7 +5,7 @@
 // gfx950 design: 256 (B rows) x 256 (A rows) x 64 block tile, 512 threads = 8 waves as 2 x 4, each wave 128 x 64 of
 // v_mfma_f32_16x16x32_bf16 tiles.  B rows ride the MFMA "M" index and A rows the "N" index, so a lane's four
 // accumulator registers are four CONSECUTIVE output columns of one C row: the epilogue is one 16-byte store per
-// lane per tile.  Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+// lane per tile.  Operand tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no VGPR round trip), double
 // buffered (2 x 64 KB); the LDS image is lane-linear 128-byte rows whose 16-byte chunks are XOR-swizzled with
 // bits 1..3 of the row — applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads —
 // which spreads the 16 rows of a fragment over all 16 slots of the 256-byte bank row.  Blocks are remapped so
@@ -33,8 +33,6 @@ static_assert(EPI_BASE_STORE + 8 * 16 * EROW <= BIAS_BASE && LDS_BYTES <= 160 * 
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char nt_smem[];
 
-#define GLDS16(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
-                                                        (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
 // block barrier that orders LDS traffic only (no wait for global loads / stores / DMA pieces in flight)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(w);      // (scalar copy for the DMA's LDS base)
     // Persistent block: rows blockIdx.x, + gridDim.x, ...  While a row is processed out of registers the next one streams
-    // into LDS by DMA (global_load_lds, 16 bytes per lane, no registers), so the HBM read overlaps the selection work.
+    // into LDS by DMA (buffer_load ... lds, 16 bytes per lane, no registers), so the HBM read overlaps the selection work.
     float* rowbuf = reinterpret_cast<float*>(rowbuf_raw);
     // (MUBUF form of the DMA and LDS-only barriers: __syncthreads() carries a release fence, i.e. a vmcnt(0) that would wait
     // for the row just requested, and FLAT-encoded global_load_lds in flight turns every LDS wait into a full drain)

@@ -15,3 +15,8 @@ run --steps 5 --warmup 2 --nonlinearity topk --aux --layers 32 --d-acts 4096 --f
 # config/topk-clt.yaml: PerLayerTopK(16) + aux(512), F=20000/layer, batch 2000)
 run --steps 10 --warmup 3 --nonlinearity jumprelu --features 10000 --batch 4000
 run --steps 10 --warmup 3 --nonlinearity topk --aux --features 20000 --batch 2000
+# other batch sizes of the headline and of config 2 (B in {1024, 4096, 8192})
+run --steps 20 --warmup 5 --batch 1024
+run --steps 20 --warmup 5 --batch 8192
+run --steps 10 --warmup 3 --nonlinearity jumprelu --decoder plt --batch 1024
+run --steps 10 --warmup 3 --nonlinearity topk
