@@ -162,6 +162,56 @@ __global__ void mse_kernel(const float* __restrict__ r, const float* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// The base-loss step of the list regime in bf16 mode wants three things of the reconstruction error and nothing else: the
+// loss sum, d(loss)/d(recons) as the bf16 rows the weight pass gathers, and its column sums (the decoder bias gradient).
+// One pass instead of mse + cast + column_sum, and no fp32 gradient tensor.  Block = 64 rows x 256 columns (a wave per
+// row, 4 columns per lane); part_c: [gridDim.y][n] column partials, part_l: [gridDim.x * gridDim.y] loss partials.
+constexpr int MF_R = 64;
+__global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
+                                                              const float* __restrict__ mean, const float* __restrict__ stdv, int rows,
+                                                              int n, float gs, uint16_t* __restrict__ g16, float* __restrict__ part_c,
+                                                              double* __restrict__ part_l) {
+    __shared__ float red[4][256];
+    __shared__ double sh[4];
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + 4 * tx;
+    const int r0 = blockIdx.y * MF_R;
+    const bool cin = col < n;
+    float4 mu = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sd = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (cin) { mu = *reinterpret_cast<const float4*>(mean + col); sd = *reinterpret_cast<const float4*>(stdv + col); }
+    float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    double acc = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < MF_R / 4; ++i) {
+        const int row = r0 + w + 4 * i;
+        if (!cin || row >= rows) continue;
+        const float4 rv = *reinterpret_cast<const float4*>(r + (long)row * n + col);
+        const float4 yv = *reinterpret_cast<const float4*>(y + (long)row * yrs + col);
+        const float d0 = rv.x - (yv.x - mu.x) / sd.x, d1 = rv.y - (yv.y - mu.y) / sd.y;
+        const float d2 = rv.z - (yv.z - mu.z) / sd.z, d3 = rv.w - (yv.w - mu.w) / sd.w;
+        const float g0 = gs * d0, g1 = gs * d1, g2 = gs * d2, g3 = gs * d3;
+        cs[0] += g0; cs[1] += g1; cs[2] += g2; cs[3] += g3;
+        acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+        *reinterpret_cast<uint2*>(g16 + (long)row * n + col) =
+            make_uint2((uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16), (uint32_t)f32_to_bf16(g2) | ((uint32_t)f32_to_bf16(g3) << 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[w][4 * tx + k] = cs[k];
+    const double s = block_sum_d(acc, sh);                 // (contains the barrier that also publishes red[])
+    if (threadIdx.x == 0) part_l[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n) part_c[(long)blockIdx.y * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// out[c] (+)= sum over chunks of part[chunk][c], fixed order
+__global__ void sum_chunks_kernel(const float* __restrict__ part, int nchunks, int n, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nchunks; ++k) s += part[(long)k * n + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
 __global__ void aux_mse_kernel(const float* __restrict__ ar, const float* __restrict__ ys, const float* __restrict__ r,
                                long total, float gs, float* __restrict__ ga, float* __restrict__ gm,
                                double* __restrict__ part) {
@@ -652,6 +702,25 @@ int clt_mse_f32(const float* r, const float* y, long yrs, const float* mean, con
     const int nb = blocks_for(total, TPB * 8, 2048);
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(TPB), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g, ys_out, (double*)ws);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)ws, nb, 1, loss_sum);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n) {
+    const size_t chunks = (size_t)(rows + MF_R - 1) / MF_R, ctiles = (size_t)(n + 255) / 256;
+    return chunks * ctiles * sizeof(double) + chunks * (size_t)n * sizeof(float);
+}
+int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n, float gs,
+                            uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* ws, size_t wsb, void* st) {
+    if (rows <= 0 || n <= 0 || yrs < n || !g16 || !colsum || !loss_sum) return CLT_ERR_SHAPE;
+    if (n % 4 || yrs % 4 || !aligned16(r) || !aligned16(y) || !aligned16(mean) || !aligned16(stdv) || (reinterpret_cast<uintptr_t>(g16) & 7))
+        return CLT_ERR_ALIGN;
+    if (!ws || wsb < clt_mse_bf16_colsum_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    const int chunks = (rows + MF_R - 1) / MF_R, ctiles = (n + 255) / 256;
+    double* part_l = (double*)ws;
+    float* part_c = (float*)(part_l + (size_t)chunks * ctiles);
+    hipLaunchKernelGGL(mse_bf16_colsum_kernel, dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
+                       part_c, part_l);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)part_l, chunks * ctiles, 1, loss_sum);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(st), (const float*)part_c, chunks, n, colsum, accumulate);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_aux_mse_f32(const float* ar, const float* ys, const float* r, long total, float gs, float* ga, float* gm,

@@ -338,6 +338,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
 }
 
+// ablation switches of the kernel (CLT_GEMM_DIAG, read once): 1 no stores, 2 no k loop, 16 no select epilogue, 32 nothing passes
+// the select epilogue's fast reject
+int gemm_diag() {
+    static const int d = getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0;
+    return d;
+}
+
 // per-lane DMA offsets are 32-bit byte offsets from the tile's first row (+ the k offset in the scalar offset)
 bool dma_offsets_fit(long lda, long ldb, long K) { return (255 * (lda > ldb ? lda : ldb) + K) * 2 < 0x7fffffffL; }
 
@@ -370,7 +377,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
                        lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
-                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0, SelEpi{}, Bseg, kts, grp);
+                       gemm_diag(), SelEpi{}, Bseg, kts, grp);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
@@ -411,7 +418,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
                        (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk,
-                       getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0,
+                       gemm_diag(),
                        SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0,
                        (const GemmGroup*)nullptr);
     CLT_LAUNCH_CHECK();

@@ -118,7 +118,7 @@ template <int NPT>
 __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
                                                            int32_t* __restrict__ idx_out, float* __restrict__ val_out,
                                                            const uint8_t* __restrict__ col_mask, int L,
-                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows, int diag) {
+                                                           uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows) {
     __shared__ uint2 red[2][RW];
     __shared__ uint32_t ckey[RCAP];
     __shared__ int32_t cidx[RCAP];                         // feature index of each candidate
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     }
     LDS_BARRIER();                                        // every thread holds its keys: the buffer may be refilled
     if (row + gridDim.x < nrows) prefetch(row + gridDim.x);
-    if (diag & 1) { if (tmax == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }     // (ablation: streaming + key extraction only)
     // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
     // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
     uint32_t LB = 0;
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
 #pragma unroll
         for (int i = 1; i < RW; ++i) LB = min(LB, wlb[i]);
     }
-    if (diag & 2) { if (LB == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }        // (ablation: + lower bound)
     // (key, index) pairs of the candidates go to LDS in arrival order: per register slot one ballot — nearly always
     // empty, k << F — and one LDS atomic per wave that has any; the exact search does not depend on the order
 #pragma unroll
@@ -291,7 +289,6 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
             if (sum >= (uint32_t)k) T = cand;
         }
     }
-    if (diag & 4) { if (T == 0x12345u) val_out[0] = 1.0f; LDS_BARRIER(); continue; }         // (ablation: + exact k-th value)
     // counts above / at T (the single-wave search already has them)
     uint32_t ngt = 0, neq = 0;
     if (total <= 64u) { ngt = cnt_sh[0]; neq = cnt_sh[1]; }
@@ -531,7 +528,7 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         const int grid = rows < cus ? rows : cus;
         const size_t dyn = (size_t)((F + 4095) / 4096) * 4096 * 4;           // whole 16 KB DMA rounds
 #define TKR(NPT_) do { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_reg_kernel<NPT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return CLT_ERR_LAUNCH; \
-        hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows, getenv("CLT_TOPK_DIAG") ? atoi(getenv("CLT_TOPK_DIAG")) : 0); } while (0)
+        hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows); } while (0)
         const int per = (F + RT - 1) / RT;
         if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 16) TKR(16); else TKR(32);
 #undef TKR

@@ -95,6 +95,8 @@ COMPACT_AUX_MAX_SHARE = 0.5
 FUSE_DENSE_JUMPRELU = True
 #: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
 FUSE_WEIGHT_PREP = True
+#: list regime, bf16 mode, base loss: loss sum + bf16 gradient rows + decoder bias gradient in one pass over the error
+FUSE_MSE_BF16 = True
 
 
 def _encoder_operand(enc):
@@ -274,16 +276,16 @@ class _Decoder:
         return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt,
                                                    w_bf16=self.shadow))
 
-    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None):
+    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
         Returns (dval [S.cap], dval2 [S2.cap] or None).  extra = ({name: compact dW}, map): dense gradient of the
         compacted aux pass, added to the mapped rows."""
-        dev = g.device
+        dev = S.csc_val.device
         slots = self.L if self.clt else 1
         dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
         dots2 = torch.empty(slots, S2.cap, dtype=torch.float32, device=dev) if S2 is not None else None
         if self.bf16:                      # bf16 mode: gathered g rows as bf16 (fp32 accumulate), half the gather bytes
-            g = ops.cast_bf16(g)
+            g = g16 if g16 is not None else ops.cast_bf16(g)      # (g16: the loss kernel already wrote the bf16 rows)
             g2 = ops.cast_bf16(g2) if g2 is not None else None
         second = (S2, S2.csc_val, g2) if S2 is not None else None
         for l, (name, w) in enumerate(zip(self.names(), self.W32)):
@@ -388,7 +390,13 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     else:
         r = D.fwd(feat)
         fired = ops.column_any_positive(feat)
-    loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
+    g16 = b_grad = None
+    fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and sparse and bf16 and kind == "base") else None
+    if fm is not None:                       # loss + bf16 gradient rows + decoder bias gradient in one pass, no fp32 gradient
+        loss_sum, g16, b_grad = fm
+        g = ys = None
+    else:
+        loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
     terms = {"mse": (loss_sum[0] / N).float()}
     dead, dead_cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
     if shard is not None:                     # features are split over ranks: count over all shards
@@ -442,7 +450,10 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             grads["decoder.b"] = ops.column_sum(g_aux)
         else:
             loss = terms["mse"]
-        grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
+        if b_grad is not None:
+            grads["decoder.b"] = b_grad
+        else:
+            grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
         xsrc = xs16 if bf16 else xs32
         extra_dec = extra_enc = None
         if cx is not None:
@@ -457,7 +468,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                 dWt_c = ops.encoder_wgrad(xs32, dpre_c)
             extra_dec = (gc, cmap)
             extra_enc = (dWt_c.view(-1, d), cmap, ops.column_sum(dpre_c).view(-1))
-        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec)
+        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16)
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
         db = torch.empty(L, F, dtype=torch.float32, device=xs32.device)

@@ -491,6 +491,22 @@ def mse(r, y, mean, std, want_grad=True, want_ys=False):
     return loss_sum, g, ys
 
 
+def mse_bf16_colsum(r, y, mean, std):
+    """Base loss of the list regime in bf16 mode, one pass: (loss_sum fp64 [1], g16 = bf16 2/(B*L*d) * (r - ys),
+    column sums of that gradient in fp32 = the decoder bias gradient).  None when the layout does not qualify."""
+    _chk(r); _chk(y, contiguous=False); _chk(mean); _chk(std)
+    rows, n, rs = _rows_view(y)
+    if n % 4 or rs % 4 or y.data_ptr() % 16:
+        return None
+    g16 = torch.empty(r.shape, dtype=torch.bfloat16, device=r.device)
+    colsum = torch.empty(mean.shape, dtype=torch.float32, device=r.device)
+    loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
+    ws = workspace(lib.clt_mse_bf16_colsum_workspace_bytes(rows, n), r.device)
+    call("clt_mse_bf16_colsum_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (rows * n),
+         g16.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return loss_sum, g16, colsum
+
+
 def aux_mse(aux_r, ys, r, g_main, scale: float):
     """g_aux = scale*2/N * e (finite only); g_main += g_aux in place.  Returns (aux_sum fp64 [1], g_aux)."""
     for t in (aux_r, ys, r, g_main):

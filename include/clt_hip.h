@@ -124,6 +124,13 @@ size_t clt_reduce_workspace_bytes(long count);
 int clt_mse_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std,
                 int rows, int n, float grad_scale, float* g, float* ys_out, double* loss_sum,
                 void* workspace, size_t ws_bytes, void* stream);
+/* The same loss, with the gradient leaving only as what the list regime's backward reads in bf16 mode: g16 = bf16 rows of
+ * 2/(B*L*d) * (r - standardize(y)) and colsum[n] (+)= their fp32 column sums (the decoder bias gradient) — mse + cast +
+ * column sum in one pass, no fp32 gradient tensor.  n % 4 == 0, 16-byte aligned rows. */
+size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n);
+int clt_mse_bf16_colsum_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std, int rows,
+                            int n, float grad_scale, uint16_t* g16, float* colsum, int accumulate, double* loss_sum,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* TopK aux loss — clt_lightning.py:548-553: e = aux_r - (ys - r); aux_sum = sum nan_to_num(e^2);
  * g_aux = grad_scale*e*[isfinite(e^2)];  g_main += g_aux (recons_err is not detached). */
 int clt_aux_mse_f32(const float* aux_r, const float* ys, const float* r, long count, float grad_scale,

@@ -1,4 +1,4 @@
-"""Time clt_topk_rows_f32 (list output only) on a [B*L, F] tensor; CLT_TOPK_DIAG selects the ablation."""
+"""Time clt_topk_rows_f32 (list output only) on a [B*L, F] tensor:  topk_probe.py [F] [k]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -15,4 +15,4 @@ for it in range(10):
     lib.clt_topk_rows_f32(x.data_ptr(), None, rows, F, k, idx.data_ptr(), val.data_ptr(), st)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
-print(f"diag={os.environ.get('CLT_TOPK_DIAG', '0')} F={F}: {ms:.3f} ms  ({rows * F * 4 / ms / 1e6:.0f} GB/s)")
+print(f"F={F} k={k}: {ms:.3f} ms  ({rows * F * 4 / ms / 1e6:.0f} GB/s)")

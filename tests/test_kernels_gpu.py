@@ -582,3 +582,18 @@ def test_weight_prep_one_pass(ops, nb, rows, n):
     ops.weight_prep_bf16(w, sq2, False)
     assert torch.allclose(sq2[: nb * rows], (w.double() ** 2).sum(-1).reshape(-1).float(), rtol=1e-6, atol=0)
     assert ops.weight_prep_bf16(_rand(1, 12, 768, seed=1).to(DEV)) is None          # rows % 8 != 0: caller falls back
+
+
+@pytest.mark.parametrize("B,L,d", [(130, 3, 72), (64, 2, 128), (257, 1, 260)])
+def test_mse_bf16_colsum_one_pass(ops, B, L, d):
+    """clt_mse_bf16_colsum_f32 == clt_mse_f32 + cast_bf16 + column_sum: bf16 gradient rows bit-exact, sums to fp32 rounding."""
+    batch = _rand(B, 2, L, d, seed=41).to(DEV)
+    r = _rand(B, L, d, seed=42).to(DEV)
+    mean, std = _rand(L, d, seed=43).to(DEV), (_rand(L, d, seed=44).abs() + 0.5).to(DEV)
+    y = batch[:, 1]                                            # strided rows, as the step hands them over
+    loss, g, _ = ops.mse(r, y, mean, std, True, False)
+    loss2, g16, colsum = ops.mse_bf16_colsum(r, y, mean, std)
+    assert torch.equal(g16, ops.cast_bf16(g))
+    assert torch.allclose(loss2, loss, rtol=1e-12, atol=0)
+    ref = g.double().sum(0).float()
+    assert torch.allclose(colsum, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
