@@ -339,8 +339,11 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if sparse and not (topk_family and kind in ("base", "topk")):
         raise NotImplementedError("the sparse regime covers TopK-family sparsifiers with the base / TopK-aux losses")
 
-    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, True, bf16)
+    # (the fp32 standardized activations are read only by the fp32 mode, the dense regime and the compacted aux pass)
+    need_xs32 = not (bf16 and sparse and kind == "base")
+    xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, need_xs32, bf16)
     xo = xs16 if bf16 else xs32
+    dev = batch.device
     shard = getattr(mod, "shard", None)
     if shard is not None and shard.world == 1 and not shard.keep_single:
         shard = None
@@ -424,10 +427,10 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                     # gathered weights (fp32 + bf16 + bf16 transposed) + their fp32 gradients + compact activations
                     rows_c = sum(w.shape[0] for w in D.W32) * cx[0]
                     need = rows_c * d * 12 + Bn * L * cx[0] * 16
-                    if need > 0.8 * torch.cuda.mem_get_info(xs32.device)[0]:
+                    if need > 0.8 * torch.cuda.mem_get_info(dev)[0]:
                         cx = None                                   # not enough HBM left: the activation-list form
                 if shard is not None:                               # both forms hold collectives: every rank takes the same one
-                    flag = torch.tensor([0 if cx is None else 1], dtype=torch.int32, device=xs32.device)
+                    flag = torch.tensor([0 if cx is None else 1], dtype=torch.int32, device=dev)
                     if int(shard.all_reduce_min(flag)) == 0:
                         cx = None
             if cx is not None:
@@ -461,7 +464,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             Dc.wgrad(feat_c, g_aux, gc)
             dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
             if bf16:
-                dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=xs32.device)
+                dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=dev)
                 ops.wgrad_t(ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn), ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L,
                             n_pad * Bn, d * Bn)
             else:
@@ -471,7 +474,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16)
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
-        db = torch.empty(L, F, dtype=torch.float32, device=xs32.device)
+        db = torch.empty(L, F, dtype=torch.float32, device=dev)
         Wt = enc.Wt
         kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None, extra=extra_enc)
         if optimizer is not None:
