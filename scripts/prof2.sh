@@ -12,6 +12,6 @@ for cfg in "${CF[@]}"; do
   find gpurun_out/prof_$name -name '*kernel_stats.csv' | head -1 | xargs -r python3 -c "
 import csv,sys
 for i,r in enumerate(csv.DictReader(open(sys.argv[1]))):
-    if i<18: print(r['Name'][:70].ljust(70), r['Calls'].rjust(5), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9), r['Percentage'])
+    if i<32: print(r['Name'][:70].ljust(70), r['Calls'].rjust(5), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9), r['Percentage'])
 "
 done
