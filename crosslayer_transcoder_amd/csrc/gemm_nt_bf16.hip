@@ -203,7 +203,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         fb[r & 7] = ldB(base, r >> 3, r & 7);
                     } else if (!LAST) {
                         if (r == 16) {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            if (diag & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (ablation: no wait for the DMA — wrong results)
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                             if (kt + 2 < nk) stage(kt & 1, kt + 2);
 #pragma unroll
                             for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nbase, 0, n);
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
 }
 
-// ablation switches of the kernel (CLT_GEMM_DIAG, read once): 1 no stores, 2 no k loop, 16 no select epilogue, 32 nothing passes
-// the select epilogue's fast reject
+// ablation switches of the kernel (CLT_GEMM_DIAG, read once): 1 no stores, 2 no k loop, 4 no wait for the DMA pieces (wrong
+// results), 16 no select epilogue, 32 nothing passes the select epilogue's fast reject
 int gemm_diag() {
     static const int d = getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0;
     return d;
