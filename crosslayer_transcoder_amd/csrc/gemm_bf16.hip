@@ -147,7 +147,7 @@ extern "C" int clt_gemm_bf16(const uint16_t* A, const uint16_t* B, float* C, int
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CLT_ERR_SHAPE;
     if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return CLT_ERR_SHAPE;
     if ((long)((M + BM - 1) / BM) > 65535 || batch > 65535) return CLT_ERR_RANGE;
-    if (!transA && transB) {                       // k-contiguous operands: the glds / 16x16x32 fast path
+    if (!transA && transB) {                       // k-contiguous operands: the LDS-DMA / 16x16x32 fast path
         const int rc = clt_internal_gemm_nt_bf16(A, B, C, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias, sBias, accumulate,
                                                  as_stream(stream));
         if (rc <= 0) return rc;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         return t;
     };
 
-    // ---- staging addresses: per glds instruction a wave fills 8 rows x 128 B ---------------------------
+    // ---- staging addresses: per DMA piece a wave fills 8 rows x 128 B ---------------------------
     // B may be K-SEGMENTED (Bseg != nullptr): k-tiles [s*kts, (s+1)*kts) of the contraction come from the matrix at
     // Bseg[s] (same ldb) — the cross-layer decoder's feature gradient sums over target layers, i.e. contracts over
     // (target layer, d_acts) with one weight tensor per target layer, and is then written once instead of accumulated

@@ -128,7 +128,7 @@ class _CompactDecoder:
 class _Decoder:
     """Decoder passes for either decoder class.  Dense passes take fp32 tensors and form their GEMM operands in
     the active precision: fp32 -> the exact-fp32 MFMA kernel on the natural layouts; bf16 -> every contraction in
-    the k-contiguous "NT" form of the glds MFMA kernel, with transposed bf16 copies where the natural layout has
+    the k-contiguous "NT" form of the LDS-DMA MFMA kernel, with transposed bf16 copies where the natural layout has
     the contraction index outermost (decoder forward: weights^T; weight gradients: features^T and g^T)."""
 
     def __init__(self, dec, shard=None, shadow=False, clt=None):

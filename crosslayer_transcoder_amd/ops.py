@@ -250,7 +250,7 @@ def plt_decoder_wgrad(feat, g, out=None, accumulate=False):
 
 
 # ---- dense decoder / encoder-wgrad contractions with every operand k-contiguous (bf16 fast path) -------------
-# The glds MFMA kernel wants both operands k-contiguous ("NT").  Contractions whose natural layout is not
+# The LDS-DMA MFMA kernel wants both operands k-contiguous ("NT").  Contractions whose natural layout is not
 # (decoder forward: K = features, weights stored [F][d]; weight gradients: K = tokens) get a transposed bf16
 # copy of one operand (cast_transpose_bf16) — the cast to bf16 is needed anyway.
 def transpose_cast_2d(x: torch.Tensor) -> torch.Tensor:
