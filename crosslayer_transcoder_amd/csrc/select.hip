@@ -530,7 +530,8 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
 #define TKR(NPT_) do { if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_reg_kernel<NPT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return CLT_ERR_LAUNCH; \
         hipLaunchKernelGGL((topk_rows_reg_kernel<NPT_>), dim3(grid), dim3(RT), dyn, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt, col_cnt, (long)rows); } while (0)
         const int per = (F + RT - 1) / RT;
-        if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 16) TKR(16); else TKR(32);
+        if (per <= 4) TKR(4); else if (per <= 8) TKR(8); else if (per <= 12) TKR(12); else if (per <= 16) TKR(16);
+        else if (per <= 20) TKR(20); else if (per <= 24) TKR(24); else TKR(32);
 #undef TKR
     } else
         hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt,

@@ -146,7 +146,8 @@ def test_selection_golden(ops, golden):
 
 
 @pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (1, 1, 5, 3), (2, 8, 10, 3), (1, 12, 768, 3), (10, 1, 3, 3),
-                                     (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8)])
+                                     (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
+                                     (8, 2, 10000, 16), (8, 2, 20000, 16), (6, 2, 24000, 70), (5, 1, 32768, 300)])
 def test_selection_vs_oracle(ops, B, L, F, k):
     x = _rand(B, L, F, seed=B + F)
     xd = x.to(DEV)
@@ -404,7 +405,7 @@ def _lists_equal(A, Bl, what):
 
 
 @pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (16, 2, 32, 4), (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
-                                     (2, 2, 64, 64), (512, 4, 8192, 16)])
+                                     (2, 2, 64, 64), (512, 4, 8192, 16), (16, 2, 20000, 16), (8, 2, 12000, 100)])
 def test_select_lists_matches_dense_selection(ops, B, L, F, k):
     """Selection straight to lists == dense (oracle-checked) selection followed by the list build, bit for bit,
     in every mode, with and without the dead-feature mask; EMA thresholds agree."""
