@@ -505,6 +505,82 @@ SegPlan plan(int B, int L, int F, int per_layer) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// mode 0, short rows with dense output (F <= 6144: the compacted dead columns of the TopK-aux pass, k = 512): one WAVE per
+// row, the row's keys in registers, no LDS and no block barrier.  The exact k-th largest key comes from a bit-by-bit search
+// (one threshold per step: per-lane compare-and-count over the registers, one wave reduction); a block that owns a row
+// pays ~20 barriers per row for the same search, which at 20 KB per row is all of its time.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+template <int J>                                       // float4 groups per lane: F <= 256 * J
+__global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
+                                                             const uint8_t* __restrict__ col_mask, int L, long nrows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;                          // (whole waves leave; nothing below synchronises the block)
+    const float* xr = x + row * F;
+    const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+    uint32_t key[J * 4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i0 = (j * 64 + lane) * 4;
+        const bool in = i0 < F;
+        const int ic = in ? i0 : 0;
+        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
+        float a[4] = {v.x, v.y, v.z, v.w};
+        if (mk) {
+            const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
+            a[0] = m4.x ? a[0] : -INFINITY; a[1] = m4.y ? a[1] : -INFINITY; a[2] = m4.z ? a[2] : -INFINITY; a[3] = m4.w ? a[3] : -INFINITY;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) key[j * 4 + c] = in ? f32_key(a[c]) : 0u;
+    }
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int e = 0; e < J * 4; ++e) c += key[e] >= cand ? 1u : 0u;
+        if (wave_sum_u32(c) >= (uint32_t)k) T = cand;
+    }
+    uint32_t cgt = 0, ceq = 0;
+#pragma unroll
+    for (int e = 0; e < J * 4; ++e) { cgt += key[e] > T ? 1u : 0u; ceq += key[e] == T ? 1u : 0u; }
+    const uint32_t ngt = wave_sum_u32(cgt), neq = wave_sum_u32(ceq), krem = (uint32_t)k - ngt;
+    const bool rank_ties = neq != krem && key_f32(T) > 0.0f;      // more ties than places: the lower indices win
+    uint32_t running = 0;
+    float* fr = feat + row * F;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i0 = (j * 64 + lane) * 4;
+        uint32_t before = 0;
+        if (rank_ties) {                               // (wave-uniform) index order = group, lane, element
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += key[j * 4 + c] == T ? 1u : 0u;
+            uint32_t sc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)sc, o, 64); if (lane >= o) sc += t; }
+            before = running + sc - mine;
+            running += (uint32_t)__shfl((int)sc, 63, 64);
+        }
+        float o4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t kk = key[j * 4 + c];
+            bool sel = kk > T;
+            if (kk == T) { sel = rank_ties ? before < krem : true; ++before; }
+            const float v = key_f32(kk);
+            o4[c] = (sel && v > 0.0f) ? v : 0.0f;
+        }
+        if (i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
                            const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st) {
     if (rows <= 0 || F <= 0 || k < 0 || L <= 0) return CLT_ERR_SHAPE;
@@ -519,6 +595,16 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
     }
     const bool reg_ok = F % 4 == 0 && F <= 32 * RT && (!idx_out || k <= 1024) && aligned16(x) && (!feat || aligned16(feat)) &&
                         (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !getenv("CLT_TOPK_ROWS_V1");
+    // (measured, 49152 rows: F = 5632 k = 512: 2.07 -> 1.30 ms; F = 2048 k = 16: 4.40 -> 0.31 ms; at F = 8192 the 128 keys per
+    // lane leave one wave per SIMD and the block kernel is faster)
+    if (reg_ok && feat && !idx_out && !row_cnt && !col_cnt && F <= 6144 && !getenv("CLT_TOPK_NO_WAVE")) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+#define TKW(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_>), grid, dim3(256), 0, st, x, feat, F, k, col_mask, L, (long)rows)
+        const int groups = (F + 255) / 256;
+        if (groups <= 4) TKW(4); else if (groups <= 8) TKW(8); else if (groups <= 16) TKW(16); else TKW(24);
+#undef TKW
+        CLT_LAUNCH_CHECK(); return CLT_OK;
+    }
     if (reg_ok) {
         static int cus = 0;
         if (!cus) {
