@@ -506,7 +506,8 @@ SegPlan plan(int B, int L, int F, int per_layer) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// mode 0, short rows with dense output (F <= 6144: the compacted dead columns of the TopK-aux pass, k = 512): one WAVE per
+// mode 0, short rows (F <= 6144: the compacted dead columns of the TopK-aux pass, k = 512; a rank's slice of the features
+// under sharding; small dictionaries), dense and / or list output: one WAVE per
 // row, the row's keys in registers, no LDS and no block barrier.  The exact k-th largest key comes from a bit-by-bit search
 // (one threshold per step: per-lane compare-and-count over the registers, one wave reduction); a block that owns a row
 // pays ~20 barriers per row for the same search, which at 20 KB per row is all of its time.
@@ -518,7 +519,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 template <int J>                                       // float4 groups per lane: F <= 256 * J
 __global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
-                                                             const uint8_t* __restrict__ col_mask, int L, long nrows) {
+                                                             int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                             const uint8_t* __restrict__ col_mask, int L,
+                                                             uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;                          // (whole waves leave; nothing below synchronises the block)
@@ -552,8 +555,8 @@ __global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __rest
     for (int e = 0; e < J * 4; ++e) { cgt += key[e] > T ? 1u : 0u; ceq += key[e] == T ? 1u : 0u; }
     const uint32_t ngt = wave_sum_u32(cgt), neq = wave_sum_u32(ceq), krem = (uint32_t)k - ngt;
     const bool rank_ties = neq != krem && key_f32(T) > 0.0f;      // more ties than places: the lower indices win
-    uint32_t running = 0;
-    float* fr = feat + row * F;
+    uint32_t running = 0, run_out = 0;
+    float* fr = feat ? feat + row * F : nullptr;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int i0 = (j * 64 + lane) * 4;
@@ -577,7 +580,27 @@ __global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __rest
             const float v = key_f32(kk);
             o4[c] = (sel && v > 0.0f) ? v : 0.0f;
         }
-        if (i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        if (idx_out) {                                 // list output: places in feature order from an ordered wave scan
+            uint32_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mine += o4[c] > 0.0f ? 1u : 0u;
+            uint32_t sc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)sc, o, 64); if (lane >= o) sc += t; }
+            uint32_t p = run_out + sc - mine;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (o4[c] > 0.0f) {
+                    idx_out[row * k + p] = i0 + c; val_out[row * k + p] = o4[c]; ++p;
+                    if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + i0 + c], 1u);
+                }
+            run_out += (uint32_t)__shfl((int)sc, 63, 64);
+        }
+        if (fr && i0 < F) *reinterpret_cast<float4*>(fr + i0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    if (idx_out) {
+        for (int e = (int)run_out + lane; e < k; e += 64) { idx_out[row * k + e] = -1; val_out[row * k + e] = 0.0f; }
+        if (row_cnt && lane == 0) row_cnt[row] = run_out;
     }
 }
 
@@ -597,9 +620,12 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
                         (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !getenv("CLT_TOPK_ROWS_V1");
     // (measured, 49152 rows: F = 5632 k = 512: 2.07 -> 1.30 ms; F = 2048 k = 16: 4.40 -> 0.31 ms; at F = 8192 the 128 keys per
     // lane leave one wave per SIMD and the block kernel is faster)
-    if (reg_ok && feat && !idx_out && !row_cnt && !col_cnt && F <= 6144 && !getenv("CLT_TOPK_NO_WAVE")) {
+    // (list output, F = 4096 k = 16: the block kernel's rank-counting tail is faster, 1.0 vs 1.17 ms; at F <= 2048 its fixed cost
+    // per row dominates: 4.5 vs 0.36 ms)
+    if (reg_ok && (F <= 2048 || (!idx_out && F <= 6144)) && !getenv("CLT_TOPK_NO_WAVE")) {
         const dim3 grid((unsigned)((rows + 3) / 4));
-#define TKW(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_>), grid, dim3(256), 0, st, x, feat, F, k, col_mask, L, (long)rows)
+#define TKW(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
+                                   row_cnt, col_cnt, (long)rows)
         const int groups = (F + 255) / 256;
         if (groups <= 4) TKW(4); else if (groups <= 8) TKW(8); else if (groups <= 16) TKW(16); else TKW(24);
 #undef TKW
