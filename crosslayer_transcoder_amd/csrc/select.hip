@@ -174,14 +174,17 @@ __global__ __launch_bounds__(RT) void topk_rows_reg_kernel(const float* __restri
     if (row + gridDim.x < nrows) prefetch(row + gridDim.x);
     // lower bound of the k-th largest key: every wave holds at least m = ceil(k / 16) keys >= the m-th largest of its 64
     // per-thread maxima, so the minimum of those over the 16 waves is reached by at least k keys (k <= 1024)
+    // (rows shorter than 4096: only the waves whose first group of 256 indices lies inside the row take part — an empty
+    // wave would drag the bound to zero — and each of them then owes ceil(k / n_act) keys)
     uint32_t LB = 0;
-    if (k <= RT) {
-        const uint32_t mth = wave_kth(tmax, (uint32_t)(k + RW - 1) / RW);
+    const int n_act = F >= 4 * RT ? RW : F / 256;
+    if (k <= RT && n_act > 0) {
+        const uint32_t mth = w < n_act ? wave_kth(tmax, (uint32_t)(k + n_act - 1) / n_act) : 0xffffffffu;
         if (lane == 0) wlb[w] = mth;
     }
     // candidates >= LB, compacted into LDS
     LDS_BARRIER();
-    if (k <= RT) {
+    if (k <= RT && n_act > 0) {
         LB = wlb[0];
 #pragma unroll
         for (int i = 1; i < RW; ++i) LB = min(LB, wlb[i]);

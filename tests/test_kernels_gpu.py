@@ -147,7 +147,8 @@ def test_selection_golden(ops, golden):
 
 @pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (1, 1, 5, 3), (2, 8, 10, 3), (1, 12, 768, 3), (10, 1, 3, 3),
                                      (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
-                                     (8, 2, 10000, 16), (8, 2, 20000, 16), (6, 2, 24000, 70), (5, 1, 32768, 300)])
+                                     (8, 2, 10000, 16), (8, 2, 20000, 16), (6, 2, 24000, 70), (5, 1, 32768, 300),
+                                     (40, 2, 2500, 16), (40, 2, 3072, 200), (33, 1, 2052, 700), (20, 3, 4100, 16)])
 def test_selection_vs_oracle(ops, B, L, F, k):
     x = _rand(B, L, F, seed=B + F)
     xd = x.to(DEV)
