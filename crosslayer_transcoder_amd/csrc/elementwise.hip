@@ -239,7 +239,14 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ W, int rows, int d, 
     const int lane = threadIdx.x & 63;
     const float* p = W + (long)row * d;
     float s = 0.0f;
-    for (int j = lane; j < d; j += 64) { const float v = p[j]; s += v * v; }
+    if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {          // 16-byte loads (rows stay 16-byte aligned)
+        for (int j = lane * 4; j < d; j += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + j);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int j = lane; j < d; j += 64) { const float v = p[j]; s += v * v; }
+    }
     s = wave_sum(s);
     if (lane == 0) sq[row] = accumulate ? sq[row] + s : s;
 }
