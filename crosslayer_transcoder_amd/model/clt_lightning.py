@@ -112,6 +112,8 @@ class CrossLayerTranscoderModule(_Base):
         With `optimizer` (a FusedAdam) the sparse regime applies Adam to the weight matrices inside its
         backward row pass; those parameters are then absent from out["grads"]."""
         log_now = self.log_metrics_every > 0 and batch_idx % self.log_metrics_every == 0
+        if batch.dtype != torch.float32:        # the shared-memory buffer hands over fp16 (datamodule contract): widen once
+            batch = batch.float()
         with torch.no_grad():
             # (weight norms are logged from the pre-update weights, as the reference does inside training_step)
             norms = _metrics.weight_norm_metrics(self.model) if log_now and batch.is_cuda else None

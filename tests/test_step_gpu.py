@@ -287,6 +287,21 @@ def test_pinned_prefetcher_and_fit_loop(golden):
         assert_close(losses[t], rec["loss"], 2e-5, 1e-7, f"fit loss {t}")
 
 
+def test_fp16_batches_through_a_logging_step(golden):
+    """The shared-memory buffer hands batches over as fp16 (data/shared_memory.py:168-214): the step — including a step
+    that logs (batch_idx % log_metrics_every == 0 reads the batch again) — equals the step on the widened batch."""
+    from tests.build_cases import build_module
+    case = golden("batchtopk_clt_base")
+    b16 = case["batches"][0].to(torch.float16).cuda()
+    res = []
+    for batch in (b16, b16.float()):
+        mod = build_module(case)
+        mod.log_metrics_every = 1
+        opt = mod.configure_optimizers()
+        res.append([float(mod.fused_train_step(batch, t, opt)) for t in range(2)])
+    assert res[0] == res[1]
+
+
 @pytest.mark.parametrize("fused", [False, True], ids=["training_step", "fused-adam-step"])
 @pytest.mark.parametrize("name", ["dbg_jumprelu_clt", "jumprelu_plt_notanh", "topk_clt_aux", "batchtopk_clt_base"])
 def test_logging_side_outputs_match_reference(name, fused, golden):
