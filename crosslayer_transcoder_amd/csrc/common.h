@@ -10,6 +10,13 @@
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Ablation switches read from the environment exist only in a `make DIAG=1` build; the shipped library ignores them.
+#ifdef CLT_DIAG
+#include <stdlib.h>
+static inline bool diag_env(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline bool diag_env(const char*) { return false; }
+#endif
 
 // fp32 -> bf16, round to nearest even (NaN stays NaN through the compiler's cvt on gfx950).
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {

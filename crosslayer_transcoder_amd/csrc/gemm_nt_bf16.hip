@@ -53,9 +53,14 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
-                                                           long sBias, int accumulate, int tilesA, int tilesB, int total, int diag,
+                                                           long sBias, int accumulate, int tilesA, int tilesB, int total, int diag_arg,
                                                            SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts,
                                                            const GemmGroup* __restrict__ grp) {
+#ifdef CLT_DIAG
+    const int diag = diag_arg;                          // ablation build only (make DIAG=1): see gemm_diag()
+#else
+    constexpr int diag = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
@@ -339,11 +344,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     }
 }
 
-// ablation switches of the kernel (CLT_GEMM_DIAG, read once): 1 no stores, 2 no k loop, 4 no wait for the DMA pieces (wrong
-// results), 16 no select epilogue, 32 nothing passes the select epilogue's fast reject
+// Ablation switches of the kernel: compiled in only by `make DIAG=1` (-DCLT_DIAG), where CLT_GEMM_DIAG is read once from the
+// environment: 1 no stores, 2 no k loop, 4 no wait for the DMA pieces (wrong results), 16 no select epilogue, 32 nothing
+// passes the select epilogue's fast reject.  The shipped library ignores the variable (diag is the constant 0).
 int gemm_diag() {
+#ifdef CLT_DIAG
     static const int d = getenv("CLT_GEMM_DIAG") ? atoi(getenv("CLT_GEMM_DIAG")) : 0;
     return d;
+#else
+    return 0;
+#endif
 }
 
 // per-lane DMA offsets are 32-bit byte offsets from the tile's first row (+ the k offset in the scalar offset)

@@ -620,12 +620,12 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         return CLT_OK;
     }
     const bool reg_ok = F % 4 == 0 && F <= 32 * RT && (!idx_out || k <= 1024) && aligned16(x) && (!feat || aligned16(feat)) &&
-                        (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !getenv("CLT_TOPK_ROWS_V1");
+                        (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !diag_env("CLT_TOPK_ROWS_V1");
     // (measured, 49152 rows: F = 5632 k = 512: 2.07 -> 1.30 ms; F = 2048 k = 16: 4.40 -> 0.31 ms; at F = 8192 the 128 keys per
     // lane leave one wave per SIMD and the block kernel is faster)
     // (list output, F = 4096 k = 16: the block kernel's rank-counting tail is faster, 1.0 vs 1.17 ms; at F <= 2048 its fixed cost
     // per row dominates: 4.5 vs 0.36 ms)
-    if (reg_ok && (F <= 2048 || (!idx_out && F <= 6144)) && !getenv("CLT_TOPK_NO_WAVE")) {
+    if (reg_ok && (F <= 2048 || (!idx_out && F <= 6144)) && !diag_env("CLT_TOPK_NO_WAVE")) {
         const dim3 grid((unsigned)((rows + 3) / 4));
 #define TKW(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
                                    row_cnt, col_cnt, (long)rows)

@@ -82,6 +82,10 @@ class StepOutput(dict):
         raise KeyError(key)
 
 
+#: counters the benchmark reports: steps whose encoder GEMM carried the candidate filter, and void attempts among them
+#: (the bound from the last step did not hold: the step reran the unfused GEMM + selection)
+STATS = {"fused_select_steps": 0, "select_fallbacks": 0}
+
 #: fuse the encoder GEMM with the BatchTopK candidate filter when last step's k-th value is known (bf16, base loss)
 FUSE_ENCODER_SELECT = True
 #: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
@@ -335,6 +339,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     kind = mod._loss_kind
     topk_family = isinstance(nl, (PerLayerTopK, BatchTopK, PerLayerBatchTopK))
     if sparse is None:
+        sparse = getattr(mod, "sparse_regime", None)
+    if sparse is None:
         sparse = topk_family and kind in ("base", "topk")
     if sparse and not (topk_family and kind in ("base", "topk")):
         raise NotImplementedError("the sparse regime covers TopK-family sparsifiers with the base / TopK-aux losses")
@@ -355,8 +361,11 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
                                           nl.e, shard)
+        STATS["fused_select_steps"] += 1
         if S is not None:
             nl._kth = kth
+        else:
+            STATS["select_fallbacks"] += 1
     if S is None:
         pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     if S is not None:

@@ -41,11 +41,33 @@ except Exception:                                      # noqa: BLE001
         def save_hyperparameters(self, *args, **kwargs):
             pass
 
+        # ---- what Lightning's manual-optimisation API offers a training_step -------------------
+        def attach_optimizers(self, conf=None):
+            """Stand-in for the trainer's optimizer set-up: keeps what configure_optimizers() returned, so that
+            optimizers() / lr_schedulers() answer as under Lightning.  Returns (optimizer, scheduler or None)."""
+            conf = self.configure_optimizers() if conf is None else conf
+            if isinstance(conf, dict):
+                self._optimizer, self._scheduler = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+            else:
+                self._optimizer, self._scheduler = conf, None
+            return self._optimizer, self._scheduler
+
+        def optimizers(self):
+            if getattr(self, "_optimizer", None) is None:
+                self.attach_optimizers()
+            return self._optimizer
+
+        def lr_schedulers(self):
+            if getattr(self, "_optimizer", None) is None:
+                self.attach_optimizers()
+            return self._scheduler
+
 
 class _StepLoss(torch.autograd.Function):
     """Connects the engine's explicit gradients to `loss.backward()`: forward returns the loss value,
-    backward hands each parameter its precomputed gradient (scaled by the incoming grad when it is not
-    the unit root gradient, e.g. under a loss scaler)."""
+    backward hands each parameter its precomputed gradient times the incoming gradient (a loss scaler or
+    `accumulate_grad_batches` multiplies the loss; `unit_root` skips that multiply for callers that guarantee
+    a unit root gradient)."""
 
     @staticmethod
     def forward(ctx, loss, unit_root, *params_and_grads):
@@ -68,8 +90,14 @@ class CrossLayerTranscoderModule(_Base):
                  lr_decay_factor: float = 1.0, compute_dead_features: bool = False,
                  compute_dead_features_every: int = 100, tokens_till_dead: int = 1_000_000, optimizer: str = "adam",
                  beta1: Optional[float] = None, beta2: Optional[float] = None, log_metrics_every: int = 50,
-                 *args, **kwargs):
+                 fused_step: bool = True, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        #: training_step runs forward + backward + Adam itself (Lightning manual optimisation): the weight matrices
+        #: are updated inside the backward row pass and no dense gradient tensor exists.  fused_step=False keeps
+        #: Lightning's automatic optimisation: training_step returns a loss whose backward() hands out materialised
+        #: gradients and the trainer calls optimizer.step() (reference clt_lightning.py:290-312 as is).
+        self.fused_step = bool(fused_step)
+        self.automatic_optimization = not self.fused_step
         self.model = model
         self.replacement_model = replacement_model      # eval-time metric objects are accepted and ignored
         self.dead_features = dead_features
@@ -81,16 +109,25 @@ class CrossLayerTranscoderModule(_Base):
         self.compute_dead_features_every = compute_dead_features_every
         self.optimizer, self.beta1, self.beta2 = optimizer, beta1, beta2
         self.log_metrics_every = log_metrics_every
-        #: loss.backward() is assumed to start from the unit gradient (Lightning's "32"/"bf16-mixed" paths);
-        #: set False when a loss scaler multiplies the loss.
-        self.assume_unit_loss_grad = True
+        #: fused_step=False only: gradients handed out by loss.backward() are multiplied by the incoming gradient
+        #: (GradScaler, accumulate_grad_batches); True skips the multiply for callers that guarantee a unit root.
+        self.assume_unit_loss_grad = False
         assert model.encoder.n_layers == model.decoder.n_layers, "Encoder and decoder must have the same number of layers"
         self.register_buffer("last_active", torch.zeros((model.encoder.n_layers, model.encoder.d_features),
                                                         dtype=torch.long))
         self.last_step = None
 
     def configure_model(self):
-        pass
+        """reference clt_lightning.py:100-119 (tensor parallelism when trainer.num_devices > 1): with an initialised
+        torch.distributed group of more than one rank, this rank keeps its F/world slice of every feature-axis tensor
+        (parallel.shard_module) and the step's exchange points go through RCCL.  `compile` stays a no-op: the kernels
+        are hand-written."""
+        import torch.distributed as dist
+        if getattr(self, "shard", None) is not None or not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() > 1:
+            from ..parallel import FeatureShard, shard_module
+            shard_module(self, FeatureShard(self.model.encoder.d_features))
 
     def forward(self, acts_norm):
         return self.model(acts_norm)
@@ -144,6 +181,17 @@ class CrossLayerTranscoderModule(_Base):
                 self.dead_features.reset()
 
     def training_step(self, batch, batch_idx):
+        """reference clt_lightning.py:290-312 / :420-475 / :519-567.  fused_step (default): the whole optimisation
+        step — forward, backward, Adam (the trainer's own optimizer and LR scheduler objects), under Lightning's
+        manual optimisation; returns the detached loss.  fused_step=False: returns a loss for loss.backward()."""
+        if self.fused_step:
+            opt = self.optimizers()
+            raw = getattr(opt, "optimizer", opt)               # LightningOptimizer wraps the FusedAdam
+            if not isinstance(raw, FusedAdam):
+                raise TypeError("fused_step=True needs the FusedAdam that configure_optimizers() returns "
+                                "(set fused_step=False to train with another optimizer)")
+            sched = self.lr_schedulers()
+            return self.fused_train_step(batch, batch_idx, raw, sched, stepper=opt)
         out = self.compute_step(batch, batch_idx)
         params = self._named_model_params()
         names = [n for n in params if n in out["grads"]]
@@ -151,17 +199,21 @@ class CrossLayerTranscoderModule(_Base):
         gs = [out["grads"][n].reshape(params[n].shape) for n in names]
         return _StepLoss.apply(out["loss"], self.assume_unit_loss_grad, *ps, *gs)
 
-    def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None, fuse_adam=True, sparse=None):
-        """fwd + bwd + Adam with no autograd bookkeeping: what bench.py times."""
+    def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None, fuse_adam=True, sparse=None,
+                         stepper=None):
+        """fwd + bwd + Adam with no autograd bookkeeping.  `stepper`: the object whose step() is called for the
+        parameters the backward pass did not update itself (Lightning's optimizer wrapper, which also counts
+        global_step; default: `optimizer`)."""
         out = self.compute_step(batch, batch_idx, optimizer if fuse_adam else None, sparse)
         params = self._named_model_params()
         for n, p in params.items():
             g = out["grads"].get(n)
             p.grad = None if g is None else g.reshape(p.shape)
-        optimizer.step()
+        (stepper if stepper is not None else optimizer).step()
         if scheduler is not None:
             scheduler.step()
-        self.global_step += 1
+        if not HAVE_LIGHTNING:
+            self.global_step += 1
         return out["loss"]
 
     def validation_step(self, batch, batch_idx):

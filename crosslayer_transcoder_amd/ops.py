@@ -14,22 +14,14 @@ from ._lib import CltError, call, lib
 
 _ws = {}
 
-#: kernel timing hook (bench.py): when a dict, selected launches are bracketed by HIP events recorded on the
-#: launch stream (= torch's current stream) and appended as name -> [(start, end, payload), ...].  No sync.
+#: kernel timing hook (bench.py's roofline pass, run AFTER its timed loop): when a dict, selected launches are bracketed
+#: by HIP events recorded on the launch stream (= torch's current stream) and appended as name -> [(start, end,
+#: payload), ...].  No sync.
 TIMING = None
-#: at most this many launches per tag carry HIP events: several hundred unresolved timing events in flight make the
-#: runtime stall once (~70 ms, when its signal pool grows) inside the timed region
-TIMING_MAX_PER_TAG = 208
-
-
-def _timing_full(tag) -> bool:
-    """Counts the launch (TIMING["#" + tag]) and says whether it goes untimed."""
-    TIMING["#" + tag] = TIMING.get("#" + tag, 0) + 1
-    return len(TIMING.get(tag, ())) >= TIMING_MAX_PER_TAG
 
 
 def _timed_call(tag, payload, name, *args):
-    if TIMING is None or _timing_full(tag):
+    if TIMING is None:
         return call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -41,7 +33,7 @@ def _timed_call(tag, payload, name, *args):
 def _timed_raw(tag, payload, name, *args) -> int:
     """Like _timed_call for entry points whose return code 1 means "shape does not qualify": returns the code."""
     fn = getattr(lib, name)
-    if TIMING is None or _timing_full(tag):
+    if TIMING is None:
         return fn(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

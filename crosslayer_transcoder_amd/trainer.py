@@ -1,7 +1,12 @@
 """Minimal YAML -> objects loader and fit loop for the reference's LightningCLI configs
 (reference main.py:12-48, config/*.yaml) when Lightning itself is not installed: the `model:` tree is
-instantiated from its class_path/init_args nodes (reference package prefix accepted), and `fit` runs the
-automatic-optimisation order: training_step -> backward -> optimizer.step -> scheduler.step."""
+instantiated from its class_path/init_args nodes (reference package prefix accepted), the `data:` node likewise
+(TensorDataModule), `trainer.precision` / `trainer.max_steps` / `seed_everything` are honoured, and `fit` drives
+`training_step` the way Lightning's loop would: with `fused_step` (default, manual optimisation) the module's
+training_step runs forward + backward + Adam itself; with `fused_step=False` the automatic-optimisation order
+training_step -> backward -> optimizer.step -> scheduler.step is run here."""
+import itertools
+import warnings
 from typing import Iterable, Optional
 
 import torch
@@ -26,28 +31,47 @@ def build_module(cfg: dict, drop_eval_metrics: bool = True):
     return build_from_config(node)
 
 
+def build_datamodule(cfg: dict):
+    """The `data:` node of a LightningCLI config (reference config/debug-cpu.yaml:79-86).  Only the file-fed
+    TensorDataModule is in scope; the streaming ActivationDataModule needs nnsight + network."""
+    node = cfg.get("data")
+    if not node:
+        return None
+    if not node["class_path"].endswith("TensorDataModule"):
+        raise NotImplementedError(f"data module {node['class_path']} is out of scope (streaming activation generation)")
+    from .data.tensor_datamodule import TensorDataModule
+    return TensorDataModule(**(node.get("init_args") or {}))
+
+
 def apply_trainer_precision(cfg: dict):
+    """`trainer.precision`: "32" and "bf16-mixed" map one to one.  "16-mixed" (fp16 autocast + GradScaler, the
+    setting of the reference's production YAMLs, config/default.yaml:13) has no fp16 kernels here: it runs as
+    bf16-mixed — bf16 operands, fp32 accumulate, no loss scaling (bf16 has fp32's exponent range, so the
+    scaler's job does not arise) — and says so once."""
     prec = str((cfg.get("trainer") or {}).get("precision", "32"))
-    set_precision({"16-mixed": "bf16-mixed"}.get(prec, prec))      # fp16+GradScaler -> bf16 (documented)
+    if prec in ("16-mixed", "16", "fp16"):
+        warnings.warn("trainer.precision '16-mixed' (fp16 + GradScaler) is run as 'bf16-mixed' by crosslayer_transcoder_amd: "
+                      "bf16 MFMA operands, fp32 accumulation, no loss scaling.  Results differ from an fp16 run at the "
+                      "bf16 tolerance (rtol 2e-2).", UserWarning, stacklevel=2)
+        prec = "bf16-mixed"
+    set_precision(prec)
 
 
-def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0", fused: bool = True,
+def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0", fused: Optional[bool] = None,
         on_step=None):
-    """Run `max_steps` optimizer steps.  `fused=False` goes through training_step/backward/step exactly
-    as Lightning's loop would; `fused=True` uses module.fused_train_step (same arithmetic, no autograd)."""
+    """Run `max_steps` optimizer steps through `module.training_step`.  fused: override module.fused_step."""
     module.to(device)
+    if fused is not None:
+        module.fused_step = bool(fused)
+        module.automatic_optimization = not module.fused_step
     module.trainer.max_steps = max_steps
-    conf = module.configure_optimizers()
-    if isinstance(conf, dict):
-        opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
-    else:
-        opt, sched = conf, None
+    module.configure_model()
+    opt, sched = module.attach_optimizers()
     losses = []
     from .data.prefetch import prefetch
-    import itertools
     for t, batch in enumerate(prefetch(itertools.islice(batches, max_steps), device)):   # pinned, double-buffered H2D
-        if fused:
-            loss = module.fused_train_step(batch, t, opt, sched)
+        if module.fused_step:
+            loss = module.training_step(batch, t)
         else:
             opt.zero_grad(set_to_none=True)
             loss = module.training_step(batch, t)
@@ -60,3 +84,25 @@ def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0"
         if on_step is not None:
             on_step(t, loss)
     return losses, opt
+
+
+def run_config(cfg, device="cuda:0", max_steps: Optional[int] = None, fused: Optional[bool] = None, tensor_file=None):
+    """`python main.py fit --config X.yaml` without LightningCLI: seed, precision, model tree, data module, fit.
+    cfg: path or loaded dict.  tensor_file overrides data.init_args.tensor_file.  Returns (module, losses)."""
+    if isinstance(cfg, str):
+        cfg = load_config(cfg)
+    if cfg.get("seed_everything") is not None:
+        torch.manual_seed(int(cfg["seed_everything"]))
+    apply_trainer_precision(cfg)
+    module = build_module(cfg)
+    dm = build_datamodule(cfg)
+    if dm is None:
+        raise ValueError("config has no data: section")
+    if tensor_file is not None:
+        dm.tensor_file = tensor_file
+    dm.setup("fit")
+    steps = int((cfg.get("trainer") or {}).get("max_steps", 1)) if max_steps is None else max_steps
+    if int((cfg.get("trainer") or {}).get("accumulate_grad_batches", 1)) != 1:
+        raise NotImplementedError("accumulate_grad_batches != 1")
+    losses, _ = fit(module, dm.train_dataloader(), steps, device, fused)
+    return module, losses

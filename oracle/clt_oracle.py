@@ -91,6 +91,11 @@ def encoder_fwd(xs: Tensor, W: Tensor, b: Tensor) -> Tensor:
     return pre
 
 
+def encoder_fwd_layer(x: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
+    """Inference path of ONE layer, model/clt.py:134-145: x [batch, seq, d_acts] -> [batch, seq, d_features]."""
+    return _q(x) @ _q(W[layer]) + b[layer]
+
+
 def encoder_bwd(xs: Tensor, dpre: Tensor) -> Tuple[Tensor, Tensor]:
     """dW[l] = xs[:,l]^T @ dpre[:,l];  db = sum_b dpre.  (No dx: the batch does not require grad.)"""
     L = xs.shape[1]
@@ -231,6 +236,21 @@ def crosslayer_decoder_bwd(feat: Tensor, Ws: List[Tensor], g: Tensor) -> Tuple[T
 def plt_decoder_fwd(feat: Tensor, W: Tensor, b: Tensor) -> Tensor:
     L = feat.shape[1]
     return torch.stack([_q(feat[:, l]) @ _q(W[l]) for l in range(L)], dim=1) + b
+
+
+def plt_decoder_fwd_layer(feat: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
+    """Inference path, model/clt.py:216-231: feat [batch, seq, F] (or [batch, seq, L, F], of which layer `layer` is
+    taken) -> [batch, seq, d_acts]."""
+    if feat.ndim == 4:
+        feat = feat[:, :, layer, :]
+    return _q(feat) @ _q(W[layer]) + b[layer]
+
+
+def crosslayer_decoder_fwd_layer(feat: Tensor, Ws: List[Tensor], b: Tensor, layer: int) -> Tensor:
+    """Inference path, model/clt.py:304-317: feat [batch, seq, from_layer = layer + 1, F] -> [batch, seq, d_acts]
+    = sum over the source layers l' <= layer of feat[:, :, l'] @ W_layer[l'], + b[layer]."""
+    d = b.shape[1]
+    return _q(feat.flatten(-2)) @ _q(Ws[layer].reshape(-1, d)) + b[layer]
 
 
 def plt_decoder_bwd(feat: Tensor, W: Tensor, g: Tensor) -> Tuple[Tensor, Tensor, Tensor]:

@@ -33,14 +33,18 @@ def gpu_case(name, fuse_adam):
     from crosslayer_transcoder_amd.parallel import FeatureShard, shard_module
     from tests.build_cases import build_module
     from tests.conftest import load_golden
-    from tests.golden_cases import assert_close
+    from tests.golden_cases import assert_close, check_first_adam_step
     case = load_golden(name)
     mod = build_module(case, "cuda:0")
     F = case["cfg"]["d_features"]
-    shard = FeatureShard(F, keep_single=KEEP_SINGLE)
-    shard_module(mod, shard)
-    conf = mod.configure_optimizers()
-    opt, sched = (conf["optimizer"], conf["lr_scheduler"]["scheduler"]) if isinstance(conf, dict) else (conf, None)
+    if KEEP_SINGLE:
+        shard = FeatureShard(F, keep_single=True)
+        shard_module(mod, shard)
+    else:
+        mod.configure_model()                 # the module contract: shards when the process group has > 1 rank
+        shard = mod.shard
+        assert shard.world == dist.get_world_size() and mod.model.encoder.d_features == F // shard.world
+    opt, sched = mod.attach_optimizers()
     sl = lambda t, ax: t if ax is None else t.narrow(ax, shard.f_off, shard.F_local)  # noqa: E731
     params = dict(mod.model.named_parameters())
     for t, rec in enumerate(case["steps"]):
@@ -56,6 +60,7 @@ def gpu_case(name, fuse_adam):
             for k, g in out["grads"].items():
                 gref = sl(rec["grads"][k], feature_axis(k))
                 assert_close(g.reshape(gref.shape), gref, 1e-4, 2e-6 * float(rec["grads"][k].abs().max()) + 1e-12, f"grad {k}")
+            check_first_adam_step(name, opt, params, case, rec, sl=lambda k, t: sl(t, feature_axis(k)))
         assert torch.equal(mod.last_active.cpu(), sl(rec["last_active"], 1)), f"last_active {t}"
         assert_close(out["terms"]["dead_fraction"], rec["logged"]["metrics/dead_features"], 1e-6, 1e-7, "dead")
         if "training/aux_loss" in rec["logged"]:

@@ -41,3 +41,29 @@ def test_sharded_schedule_through_rccl_single_rank():
     on workspace views, all-gather into the tie region, fp64 / fp32 SUMs) goes through RCCL on its own stream, ordered
     against the launch stream; results must still equal the reference goldens."""
     _launch(["--backend", "nccl"], nproc=1, port=29517)
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank environment starts two rank processes itself and relays rank 0's line
+    (n_gpus = 2, sharding wired through configure_model).  On a box with fewer GPUs than ranks it refuses unless
+    --rehearsal is given (ranks then share the GPU over gloo: a schedule rehearsal, said in the line)."""
+    import json
+    import torch
+    small = ["--features", "2048", "--batch", "512", "--layers", "3", "--d-acts", "128", "--k", "8", "--steps", "3", "--warmup", "2",
+             "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    bench = os.path.join(ROOT, "bench.py")
+    have2 = torch.cuda.device_count() >= 2
+    if not have2:
+        p = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "--rehearsal" in p.stderr
+    p = subprocess.run([sys.executable, bench, "--gpus", "2"] + ([] if have2 else ["--rehearsal"]) + small, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"].startswith("feature-shard x2")
+    assert line["rccl_ranks"] == (2 if have2 else 0)
+    assert ("REHEARSAL" in line["config"]["parallelism"]) == (not have2)
+    assert line["value"] > 0 and line["config"]["regime"] == "activation lists"

@@ -4,20 +4,23 @@ an absolute floor of 1e-6 x max|grad| (fp32 reduction-order noise), selected fea
 import pytest
 import torch
 
-from tests.golden_cases import TRAIN_CASES, assert_close
+from tests.golden_cases import TRAIN_CASES, assert_close, check_first_adam_step
 
 pytestmark = pytest.mark.gpu
 
 
 def _opt_and_sched(mod):
-    conf = mod.configure_optimizers()
-    return (conf["optimizer"], conf["lr_scheduler"]["scheduler"]) if isinstance(conf, dict) else (conf, None)
+    return mod.attach_optimizers()
 
 
-@pytest.mark.parametrize("fused", [False, True, "dense", "compact", "compact-grads"],
-                         ids=["autograd-loop", "fused-step", "fused-dense-gemm", "fused-step-compact-aux", "compact-aux-grads"])
+@pytest.mark.parametrize("fused", ["training_step", False, True, "dense", "compact", "compact-grads"],
+                         ids=["training_step", "autograd-loop", "fused-step", "fused-dense-gemm", "fused-step-compact-aux",
+                              "compact-aux-grads"])
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_training_matches_reference(name, fused, golden, monkeypatch):
+    """Modes: "training_step" = the Lightning-facing contract alone (manual optimisation: forward + backward + Adam
+    inside training_step, with the optimizer / scheduler objects of configure_optimizers()); "autograd-loop" =
+    fused_step=False under the automatic-optimisation order; the others call fused_train_step with options."""
     from tests.build_cases import build_module
     compact = isinstance(fused, str) and fused.startswith("compact")
     if compact:
@@ -29,15 +32,19 @@ def test_training_matches_reference(name, fused, golden, monkeypatch):
         monkeypatch.setattr(engine, "COMPACT_AUX_MAX_SHARE", 1e9)
     case = golden(name)
     mod = build_module(case)
+    if fused is False:
+        mod.fused_step, mod.automatic_optimization = False, True
     opt, sched = _opt_and_sched(mod)
     params = dict(mod.model.named_parameters())
     for t, rec in enumerate(case["steps"]):
         batch = case["batches"][t].cuda()
-        with torch.no_grad():                     # drive every step from the reference's parameters
-            if t > 0:
-                pass
         assert_close(torch.tensor(opt.param_groups[0]["lr"]), rec["lr"], 1e-6, 0, f"{name} lr {t}")
-        if fused == "dense":                      # TopK family through the dense MFMA GEMM regime
+        if fused == "training_step":
+            assert mod.fused_step and not mod.automatic_optimization
+            loss = mod.training_step(batch, t)
+            assert not loss.requires_grad
+            grads = {k: mod.last_step["grads"][k].reshape(p.shape) for k, p in params.items() if k in mod.last_step["grads"]}
+        elif fused == "dense":                      # TopK family through the dense MFMA GEMM regime
             loss = mod.fused_train_step(batch, t, opt, sched, fuse_adam=False, sparse=False)
             grads = {k: mod.last_step["grads"][k].reshape(p.shape) for k, p in params.items()}
         elif fused == "compact-grads":
@@ -66,7 +73,9 @@ def test_training_matches_reference(name, fused, golden, monkeypatch):
             for k, gref in rec["grads"].items():
                 if k in grads:
                     assert_close(grads[k], gref, 1e-4, 2e-6 * float(gref.abs().max()) + 1e-12, f"{name} grad {k}")
+            check_first_adam_step(name, opt, params, case, rec)
         assert torch.equal(mod.last_active.cpu(), rec["last_active"]), f"{name} last_active {t}"
+        assert mod.global_step == t + 1
         lg = rec["logged"]
         if "training/aux_loss" in lg:
             assert_close(out["terms"]["aux"], lg["training/aux_loss"], 5e-5, 1e-7, "aux")
@@ -77,10 +86,28 @@ def test_training_matches_reference(name, fused, golden, monkeypatch):
         if "threshold" in rec:
             assert_close(mod.model.nonlinearity.threshold, rec["threshold"], 1e-5, 1e-7, "threshold")
     # after 2-4 Adam steps parameters follow the reference trajectory (Adam's sign-like first steps amplify
-    # gradient noise on near-zero gradients, hence the absolute term of ~lr/5)
+    # gradient noise on near-zero gradients, hence the absolute term of ~lr/5; the tight check of the update
+    # arithmetic is check_first_adam_step above)
     lr = case["opt"]["lr"]
     for k, p in params.items():
         assert_close(p, case["final_params"][k], 1e-4, 0.3 * lr, f"{name} final {k}")
+
+
+def test_loss_backward_scales_handed_out_gradients(golden):
+    """fused_step=False (automatic optimisation): the gradients that loss.backward() hands out follow the incoming
+    gradient — a GradScaler or accumulate_grad_batches multiplies the loss (reference: plain autograd)."""
+    from tests.build_cases import build_module
+    case = golden("batchtopk_clt_base")
+    grads = []
+    for scale in (1.0, 2.0, 1.0 / 4):
+        mod = build_module(case)
+        mod.fused_step, mod.automatic_optimization = False, True
+        loss = mod.training_step(case["batches"][0].cuda(), 0)
+        (loss * scale).backward()
+        grads.append({k: p.grad.clone() for k, p in mod.model.named_parameters()})
+    for k, g in grads[0].items():
+        assert float(g.abs().max()) > 0
+        assert torch.equal(grads[1][k], 2.0 * g) and torch.equal(grads[2][k], 0.25 * g), k
 
 
 def test_module_level_autograd_matches_reference(golden):
@@ -285,6 +312,10 @@ def test_pinned_prefetcher_and_fit_loop(golden):
     losses, _ = trainer.fit(mod, list(case["batches"]), case["max_steps"])      # fewer batches than max_steps: stops early
     for t, rec in enumerate(case["steps"]):
         assert_close(losses[t], rec["loss"], 2e-5, 1e-7, f"fit loss {t}")
+    mod = build_module(case)                      # the automatic-optimisation order (fused_step=False)
+    losses, _ = trainer.fit(mod, list(case["batches"]), case["max_steps"], fused=False)
+    for t, rec in enumerate(case["steps"]):
+        assert_close(losses[t], rec["loss"], 2e-5, 1e-7, f"fit (autograd) loss {t}")
 
 
 def test_fp16_batches_through_a_logging_step(golden):
@@ -325,6 +356,7 @@ def test_logging_side_outputs_match_reference(name, fused, golden):
     if fused:
         mod.fused_train_step(batch, 0, opt, sched)
     else:
+        mod.fused_step, mod.automatic_optimization = False, True
         mod.training_step(batch, 0)
     checked = 0
     for k, want in gm["logged"].items():
