@@ -43,6 +43,8 @@ SIGNATURES = {
     "clt_mse_f32": (I, [P, P, L, P, P, I, I, F32, P, P, P, P, SZ, P]),
     "clt_mse_bf16_colsum_workspace_bytes": (SZ, [I, I]),
     "clt_mse_bf16_colsum_f32": (I, [P, P, L, P, P, I, I, F32, P, P, I, P, P, SZ, P]),
+    "clt_mse_bf16_colsum_noalloc_max_bytes": (SZ, []),
+    "clt_mse_bf16_colsum_noalloc_f32": (I, [P, P, L, P, P, I, I, F32, P, P, I, P, P]),
     "clt_aux_mse_f32": (I, [P, P, P, L, F32, P, P, P, P, SZ, P]),
     "clt_column_sum_workspace_bytes": (SZ, [I, I]),
     "clt_column_sum_f32": (I, [P, I, I, P, I, P, SZ, P]),

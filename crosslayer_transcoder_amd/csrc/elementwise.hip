@@ -2,6 +2,7 @@
 // One pass over each [B, L*F] or [B, L*d] tensor per kernel; every reduction is two-stage and
 // fixed-order, so results are bitwise reproducible run to run.
 #include <math.h>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -729,6 +730,43 @@ int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const floa
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)part_l, chunks * ctiles, 1, loss_sum);
     hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(st), (const float*)part_c, chunks, n, colsum, accumulate);
     CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+// ---- clt_mse_bf16_colsum_noalloc_f32: the same pass for callers that cannot allocate ------------------------------------
+// The partial sums of clt_mse_bf16_colsum_f32 (per-block loss partials + per-row-chunk column partials) live in a
+// file-scope device array instead of a caller workspace.  `scratch` is the HOST-side stand-in of that array: its device
+// address is resolved once per device with hipGetSymbolAddress (each GPU holds its own copy at its own address) and only
+// that address is ever handed to a kernel.
+constexpr size_t NOALLOC_SCRATCH_BYTES = 4u << 20;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static void* noalloc_scratch_ptr[NOALLOC_MAX_DEVICES];        // per device: device address of `scratch`, nullptr = not resolved yet
+static std::mutex noalloc_mu;
+
+static int noalloc_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return CLT_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(noalloc_mu);
+    if (!noalloc_scratch_ptr[dev]) {             // first call on this device (the device is current): resolve and keep
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return CLT_ERR_LAUNCH;
+        noalloc_scratch_ptr[dev] = p;
+    }
+    *out = noalloc_scratch_ptr[dev];
+    return CLT_OK;
+}
+size_t clt_mse_bf16_colsum_noalloc_max_bytes(void) { return NOALLOC_SCRATCH_BYTES; }
+int clt_mse_bf16_colsum_noalloc_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,
+                                    float gs, uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* st) {
+    if (rows <= 0 || n <= 0 || yrs < n || !g16 || !colsum || !loss_sum) return CLT_ERR_SHAPE;
+    if (n % 4 || yrs % 4 || !aligned16(r) || !aligned16(y) || !aligned16(mean) || !aligned16(stdv) || (reinterpret_cast<uintptr_t>(g16) & 7))
+        return CLT_ERR_ALIGN;
+    if (clt_mse_bf16_colsum_workspace_bytes(rows, n) > NOALLOC_SCRATCH_BYTES) return CLT_ERR_WORKSPACE;   // beyond the fixed scratch
+    void* ptr = nullptr;
+    const int rc = noalloc_scratch(&ptr);
+    if (rc != CLT_OK) return rc;
+    // Every partial the two reduction kernels read is written by the first kernel of THIS call (chunks * ctiles loss
+    // partials, chunks * n column partials), so nothing has to start at zero and the previous call's contents are inert.
+    return clt_mse_bf16_colsum_f32(r, y, yrs, mean, stdv, rows, n, gs, g16, colsum, accumulate, loss_sum, ptr, NOALLOC_SCRATCH_BYTES, st);
 }
 int clt_aux_mse_f32(const float* ar, const float* ys, const float* r, long total, float gs, float* ga, float* gm,
                     double* aux_sum, void* ws, size_t wsb, void* st) {

@@ -131,6 +131,17 @@ size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n);
 int clt_mse_bf16_colsum_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std, int rows,
                             int n, float grad_scale, uint16_t* g16, float* colsum, int accumulate, double* loss_sum,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* clt_mse_bf16_colsum_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference: same arithmetic and same results as the entry
+ * point above, but the partial sums live in a fixed 4 MiB device array owned by the library (one per GPU, held until the
+ * process ends) instead of a caller workspace; the call allocates nothing.  Returns CLT_ERR_WORKSPACE when
+ * clt_mse_bf16_colsum_workspace_bytes(rows, n) exceeds clt_mse_bf16_colsum_noalloc_max_bytes().  The first call on a
+ * device resolves the array's address (make it outside graph capture).  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams) race. */
+size_t clt_mse_bf16_colsum_noalloc_max_bytes(void);
+int clt_mse_bf16_colsum_noalloc_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std,
+                                    int rows, int n, float grad_scale, uint16_t* g16, float* colsum, int accumulate,
+                                    double* loss_sum, void* stream);
 /* TopK aux loss — clt_lightning.py:548-553: e = aux_r - (ys - r); aux_sum = sum nan_to_num(e^2);
  * g_aux = grad_scale*e*[isfinite(e^2)];  g_main += g_aux (recons_err is not detached). */
 int clt_aux_mse_f32(const float* aux_r, const float* ys, const float* r, long count, float grad_scale,
