@@ -61,6 +61,7 @@ SIGNATURES = {
     "clt_dead_update": (I, [P, I, L, P, L, P, P, P]),
     "clt_sparse_build_workspace_bytes": (SZ, [I, I, I]),
     "clt_sparse_build_f32": (I, [P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "clt_sparse_build_threshold_f32": (I, [P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_select_lists_workspace_bytes": (SZ, [I, I, I, I, I]),
     "clt_select_lists_f32": (I, [P, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_select_lists_sharded_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
@@ -77,7 +78,7 @@ SIGNATURES = {
                                      P, P, SZ, P]),
     "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
-                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P]),
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P, P, P]),
     "clt_compact_columns": (I, [P, I, I, I, P, P, P, P]),
     "clt_gather_cols_f32": (I, [P, P, I, I, I, I, F32, P, P]),
     "clt_gather_rows_f32": (I, [P, P, I, I, I, I, P, P]),
@@ -86,7 +87,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CltError(RuntimeError):

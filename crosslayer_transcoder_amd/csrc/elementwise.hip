@@ -636,7 +636,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 1; }
+int clt_abi_version(void) { return 2; }
 
 int clt_column_stats_f32(const float* x, long rs, int rows, int n, float* mean, float* stdv, void* st) {
     if (rows <= 0 || n <= 0 || rs < n) return CLT_ERR_SHAPE;

@@ -9,12 +9,27 @@ constexpr int LTPB = 256;
 // ------------------------------------------------------------------------------------------------
 // list construction
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restrict__ feat, int F, uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on) {
+// An entry of the lists is a position with feat > 0 — and, when `theta` ([L*F], JumpReLU) is given, feat > theta as
+// well: the lists of JumpReLU(feat) straight from the pre-activations (jumprelu.py:33-37: x * [(x > theta) & (x > 0)]).
+__device__ __forceinline__ bool list_entry(float x, const float* __restrict__ th, int col) { return x > 0.0f && (!th || x > th[col]); }
+
+__global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
+                                                         uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     __shared__ uint32_t sh[4];
     const float* xr = feat + (long)blockIdx.x * F;
+    const float* th = theta ? theta + (long)(blockIdx.x % L) * F : nullptr;
     uint32_t c = 0;
-    for (int i = threadIdx.x; i < F; i += LTPB) c += xr[i] > 0.0f;
+    if (F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0) {          // 16-byte loads: the pass is a plain HBM stream
+        for (int i = threadIdx.x * 4; i < F; i += LTPB * 4) {
+            const float4 x = *reinterpret_cast<const float4*>(xr + i);
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (th) t = *reinterpret_cast<const float4*>(th + i);
+            c += (x.x > 0.0f && x.x > t.x) + (x.y > 0.0f && x.y > t.y) + (x.z > 0.0f && x.z > t.z) + (x.w > 0.0f && x.w > t.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < F; i += LTPB) c += list_entry(xr[i], th, i);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
@@ -145,7 +160,7 @@ static inline void launch_scan(const uint32_t* cnt, int n, uint32_t* start, uint
 }
 
 // ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row
-__global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L,
+__global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
                                                         const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
                                                         float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow, const int32_t* __restrict__ gate, int gate_on) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
@@ -153,10 +168,11 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     const long row = blockIdx.x;
     const float* xr = feat + row * F;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* th = theta ? theta + (row % L) * F : nullptr;
     const int seg = ((F + 3) / 4 + 63) / 64 * 64;
     const int s0 = w * seg, s1 = min(F, s0 + seg);
     uint32_t c = 0;
-    for (int i = s0 + lane; i < s1; i += 64) c += xr[i] > 0.0f;
+    for (int i = s0 + lane; i < s1; i += 64) c += list_entry(xr[i], th, i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) wcnt[w] = c;
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     for (int base = s0; base < s1; base += 64) {
         const int i = base + lane;
         const float v = i < s1 ? xr[i] : 0.0f;
-        const bool p = v > 0.0f;
+        const bool p = i < s1 && list_entry(v, th, i);
         const unsigned long long m = __ballot(p);
         if (p) {
             const uint32_t pos = off + __popcll(m & ((1ull << lane) - 1ull));

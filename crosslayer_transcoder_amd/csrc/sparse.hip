@@ -117,6 +117,9 @@ struct RowPassArgs {
     // optional dense contribution for a subset of the rows (the compacted TopK-aux pass, compact.hip):
     //   grad[r,:] += extra[extra_map[col0 + r], :] ; colsum_out[col] += extra_colsum[extra_map[col]]   (map < 0: none)
     const float* extra; const int32_t* extra_map; const float* extra_colsum;
+    // optional per-row term: grad[r,:] += (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:] — the gradient that reaches a decoder
+    // row through dec_norms (clt_lightning.py:438-448; same term as clt_adam_f32's row_dnorm / row_sq)
+    const float* row_dnorm; const float* row_sq;
 };
 
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
     const long srs = (long)a.L * a.d;
     const long ro = (long)r * a.d;
     float wv[NT][W], g[NT][W];
-    const bool need_w = a.dot_out != nullptr || a.dot_out2 != nullptr || a.grad_out == nullptr;
+    const bool need_w = a.dot_out != nullptr || a.dot_out2 != nullptr || a.grad_out == nullptr || a.row_dnorm != nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int o = cb + (t * 64 + lane) * W;
@@ -227,6 +230,13 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
         }
     }
     if (a.colsum_out && lane == 0 && (CW == 1 || wave == 0)) a.colsum_out[col] = csum;
+    if (a.row_dnorm) {
+        const float cf = a.row_dnorm[col] / sqrtf(a.row_sq[col]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < W; ++c) g[t][c] += cf * wv[t][c];
+    }
     if (a.grad_out) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -285,6 +295,14 @@ __global__ void scatter_dense_kernel(const uint32_t* __restrict__ col_start, con
     for (uint32_t p = col_start[c]; p < col_start[c + 1]; ++p) out[(long)tok[p] * ncols + c] = val[p];
 }
 
+// threshold lists: once the entry count is known, everything after the row scan runs only when the lists fit `cap`
+// (above the caller's break-even the dense regime takes over and the truncated lists would be thrown away)
+__global__ void list_gate_kernel(const uint32_t* __restrict__ total, uint32_t cap, int32_t* __restrict__ gate, int32_t* __restrict__ overflow) {
+    const bool fits = *total <= cap;
+    *gate = fits ? 1 : 0;
+    if (!fits) *overflow = 1;
+}
+
 }  // namespace
 
 // dispatch on the number of 64-lane chunks a row needs
@@ -313,10 +331,11 @@ __global__ void scatter_dense_kernel(const uint32_t* __restrict__ col_start, con
 int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
-                              const int32_t* gate) {
+                              const int32_t* gate, const float* theta, bool theta_gate) {
     if (B <= 0 || L <= 0 || F <= 0 || cap == 0) return CLT_ERR_SHAPE;
     if ((unsigned long long)L * F >= 0x7fffffffull || (unsigned long long)B * L >= 0x7fffffffull) return CLT_ERR_RANGE;
     if (!ws || wsb < clt_sparse_build_workspace_bytes(B, L, F)) return CLT_ERR_WORKSPACE;
+    const bool own_gate = !gate && theta_gate;
     const int rows = B * L, ncols = L * F;
     uint32_t* row_cnt = (uint32_t*)ws;
     uint32_t* col_cnt = row_cnt + rows;
@@ -328,9 +347,14 @@ int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t c
         if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, row_cnt, gate, 1);
+    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1);
-    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, row_start, ent_col, ent_val, cap, overflow, gate, 1);
+    if (own_gate) {         // (threshold lists: the remaining kernels exit at once when the count exceeds cap)
+        int32_t* gw = (int32_t*)(long_count + 8);
+        hipLaunchKernelGGL(list_gate_kernel, dim3(1), dim3(1), 0, st, total, cap, gw, overflow);
+        gate = gw;
+    }
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, overflow, gate, 1);
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
     launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
@@ -353,7 +377,15 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
                          float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                          uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, void* stp) {
     return clt_internal_sparse_build(feat, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
-                                     total, overflow, ws, wsb, as_stream(stp), nullptr);
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, nullptr);
+}
+
+int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+                                   int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
+                                   int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb,
+                                   void* stp) {
+    return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true);
 }
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,
@@ -388,14 +420,17 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             float* colsum_out,
                             double lr,
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
-                            const float* extra, const int32_t* extra_map, const float* extra_colsum, void* stp) {
+                            const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
+                            const float* row_sq, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
+    if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
     RowPassArgs a;
     a.W = W; a.m = m; a.v = v; a.shadow = shadow; a.grad_out = grad_out; a.rows = rows; a.d = d; a.F = F; a.col0 = col0;
     a.src_bf16 = src_bf16;
     if (extra && !extra_map) return CLT_ERR_SHAPE;
     a.extra = extra; a.extra_map = extra_map; a.extra_colsum = extra ? extra_colsum : nullptr;
+    a.row_dnorm = row_dnorm; a.row_sq = row_sq;
     a.src_layer = src_layer; a.L = L; a.col_start = col_start; a.tok = tok; a.coef = coef; a.src = src;
     a.col_start2 = col_start2; a.tok2 = tok2; a.coef2 = coef2; a.src2 = src2; a.dot_out = dot_out; a.dot_out2 = dot_out2; a.dot_stride = dot_stride; a.dot_stride2 = dot_stride2;
     a.dot_slot_base = dot_slot; a.colsum_out = colsum_out;

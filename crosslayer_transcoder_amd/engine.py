@@ -101,6 +101,13 @@ FUSE_DENSE_JUMPRELU = True
 FUSE_WEIGHT_PREP = True
 #: list regime, bf16 mode, base loss: loss sum + bf16 gradient rows + decoder bias gradient in one pass over the error
 FUSE_MSE_BF16 = True
+#: thresholding sparsifiers (JumpReLU / ReLU): break-even between the activation-list regime and the dense GEMM regime as
+#: a share of the B*L*F entries that are active (L0 / F).  Below it the decoder forward is a row gather and the decoder
+#: weight gradient + Adam one fused row pass; above it (e.g. an untrained JumpReLU at theta = 0.03: ~45 % active) the
+#: MFMA GEMMs are cheaper.  The count is taken on the device (list construction); one host read of its overflow flag.
+LIST_MAX_DENSITY = 1.0 / 128
+#: after a step whose density was above the break-even, the next attempt is made this many steps later (doubling, capped)
+LIST_RETRY_FIRST, LIST_RETRY_MAX = 8, 512
 
 
 def _encoder_operand(enc):
@@ -164,6 +171,8 @@ class _Decoder:
 
     @property
     def Wop(self):
+        if self.shadow:                     # list regime: the bf16 copies the fused Adam row pass keeps current
+            return self.shadows()
         self._prep()
         if self._Wop is None:
             self._Wop = [_op(w) for w in self.W32]
@@ -196,8 +205,8 @@ class _Decoder:
             r = ops.clt_decoder_fwd(feat, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(feat, self.Wop[0], self._bias())
         return self._reduce(r)
 
-    def dgrad(self, g):
-        go = _op(g)
+    def dgrad(self, g, go=None):
+        go = _op(g) if go is None else go
         if self.clt and self.bf16:          # one K-segmented GEMM per source layer: the result is written once
             df = ops.clt_decoder_dgrad_kseg(go, self.Wop)
             if df is not None:
@@ -280,6 +289,22 @@ class _Decoder:
         return self._reduce(ops.sparse_decoder_fwd(S, self.pointer_table(), self._bias(), self.dec.d_acts, self.clt,
                                                    w_bf16=self.shadow))
 
+    def sparse_wgrad(self, S, g, grads, fused, row_term=None, g16=None):
+        """Decoder weight gradient alone from the activation lists (thresholding sparsifiers: d(loss)/d(feature) comes
+        from the dense feature-gradient GEMM there, not from per-entry dots): one row pass per weight matrix, with the
+        gradient through dec_norms (`row_term` = (dnorm, sq)) added per row, Adam in place when `fused`."""
+        if self.bf16:
+            g = g16 if g16 is not None else ops.cast_bf16(g)
+        for l, (name, w) in enumerate(zip(self.names(), self.W32)):
+            kw = dict(row_term=row_term)
+            if fused is not None:
+                kw.update(fused.begin_fused(w))
+                if self.shadow:
+                    kw["shadow"] = self.shadows()[l]
+            else:
+                grads[name] = kw["grad_out"] = torch.empty_like(w)
+            ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+
     def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
         Returns (dval [S.cap], dval2 [S2.cap] or None).  extra = ({name: compact dW}, map): dense gradient of the
@@ -306,6 +331,26 @@ class _Decoder:
         dval = ops.sparse_reduce_dots(dots, S, self.clt)
         dval2 = ops.sparse_reduce_dots(dots2, S2, self.clt) if S2 is not None else None
         return dval, dval2
+
+
+def _threshold_lists(mod, pre, theta, force: bool):
+    """Activation lists of a thresholding sparsifier (JumpReLU: theta; ReLU: None) from its pre-activations, or None
+    when more than LIST_MAX_DENSITY of the entries are active (the dense regime is then cheaper).  force: no gate."""
+    Bn, L, F = pre.shape
+    full = Bn * L * F
+    if force:
+        return ops.sparse_build_threshold(pre, theta, full)
+    if getattr(mod, "_list_skip", 0) > 0:            # recently above the break-even: no attempt this step
+        mod._list_skip -= 1
+        return None
+    S = ops.sparse_build_threshold(pre, theta, max(1, int(LIST_MAX_DENSITY * full)))
+    if ops.read_flag(S.overflow) != 0:
+        mod._list_retry = min(LIST_RETRY_MAX, 2 * getattr(mod, "_list_retry", LIST_RETRY_FIRST // 2))
+        mod._list_skip = mod._list_retry
+        STATS["list_gate_dense"] = STATS.get("list_gate_dense", 0) + 1
+        return None
+    mod._list_retry = LIST_RETRY_FIRST // 2
+    return S
 
 
 def _list_capacity(nl, Bn, L, F):
@@ -338,15 +383,21 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     bf16 = get_precision() == "bf16"
     kind = mod._loss_kind
     topk_family = isinstance(nl, (PerLayerTopK, BatchTopK, PerLayerBatchTopK))
+    # thresholding sparsifiers take the list regime when few entries are active: JumpReLU / ReLU under the JumpReLU module's
+    # losses (decoder forward + decoder weight gradient from the lists; the STE passes gradient wherever pre >= 0, so the
+    # feature gradient and the encoder stay dense GEMMs), ReLU under the base loss (everything from the lists)
+    thr_family = (isinstance(nl, (JumpReLU, ReLU)) and kind == "jumprelu") or (isinstance(nl, ReLU) and kind == "base")
     if sparse is None:
         sparse = getattr(mod, "sparse_regime", None)
+    force_lists = sparse is True
     if sparse is None:
-        sparse = topk_family and kind in ("base", "topk")
-    if sparse and not (topk_family and kind in ("base", "topk")):
-        raise NotImplementedError("the sparse regime covers TopK-family sparsifiers with the base / TopK-aux losses")
+        sparse = (topk_family and kind in ("base", "topk")) or thr_family
+    if sparse and not ((topk_family and kind in ("base", "topk")) or thr_family):
+        raise NotImplementedError("the activation-list regime covers TopK-family sparsifiers with the base / TopK-aux losses, "
+                                  "JumpReLU / ReLU with the JumpReLU module's losses and ReLU with the base loss")
 
     # (the fp32 standardized activations are read only by the fp32 mode, the dense regime and the compacted aux pass)
-    need_xs32 = not (bf16 and sparse and kind == "base")
+    need_xs32 = not (bf16 and sparse and kind == "base" and topk_family)
     xs32, xs16 = ops.standardize(resid, ist.mean, ist.std, need_xs32, bf16)
     xo = xs16 if bf16 else xs32
     dev = batch.device
@@ -368,14 +419,20 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             STATS["select_fallbacks"] += 1
     if S is None:
         pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
+    fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
+                 and (L * F) % 4 == 0)
+    if S is None and sparse and thr_family:
+        theta = nl.theta if isinstance(nl, JumpReLU) else None
+        S = _threshold_lists(mod, pre, theta, force_lists)
+        if S is None:
+            sparse = False                       # above the break-even density: dense GEMM regime for this step
     if S is not None:
         pass
     elif sparse:
         S = _select_lists(nl, pre, shard=shard)
         if batch_mode:
             nl._kth = getattr(S, "kth", None)
-    elif (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
-          and (L * F) % 4 == 0):
+    elif fuse_jump:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
         fused_ops = ops.jumprelu_fwd_bf16(pre, theta)            # (feat bf16, feat^T bf16, fired)
     elif isinstance(nl, JumpReLU):
@@ -403,7 +460,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         r = D.fwd(feat)
         fired = ops.column_any_positive(feat)
     g16 = b_grad = None
-    fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and sparse and bf16 and kind == "base") else None
+    lists_only = sparse and kind != "jumprelu"           # every gradient comes from the lists (TopK family; ReLU + base loss)
+    fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and lists_only and bf16 and kind == "base") else None
     if fm is not None:                       # loss + bf16 gradient rows + decoder bias gradient in one pass, no fp32 gradient
         loss_sum, g16, b_grad = fm
         g = ys = None
@@ -424,7 +482,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     elif fused_ops is not None:
         out.lazy = {"features": (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))}
 
-    if sparse:
+    if lists_only:
         S2 = g_aux = cx = None
         if kind == "topk":
             aux = mod.topk_aux
@@ -508,8 +566,9 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         th = theta if theta is not None else torch.zeros(1, L, F, device=pre.device)
         bw = nl._bandwidth if theta is not None else 1.0
         sq = D.sqnorms()
-        dfeat = D.dgrad(g)
-        if fused_ops is not None:
+        g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
+        dfeat = D.dgrad(g, go=g16)
+        if fused_ops is not None or (S is not None and fuse_jump):
             sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                                   mod.pre_actv_loss / (Bn * L))
         else:
@@ -517,8 +576,14 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                                                         mod.pre_actv_loss / (Bn * L))
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
-        D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
-        D.add_norm_grads(dn, sq, grads, optimizer)
+        if S is not None:
+            # list regime: dW_l[l', i, :] = sum over the tokens where feature (l', i) is active of val * g[tok, l, :], plus the
+            # row's dec_norms term — one streaming pass per decoder matrix, Adam applied in it when an optimizer is handed in
+            D.sparse_wgrad(S, g, grads, optimizer, (dn, sq), g16)
+            out["lists"] = S
+        else:
+            D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
+            D.add_norm_grads(dn, sq, grads, optimizer)
         grads["decoder.b"] = ops.column_sum(g)
         if theta is not None:
             grads["nonlinearity.theta"] = dth

@@ -686,6 +686,39 @@ def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
     return s
 
 
+def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int) -> SparseLists:
+    """Lists of JumpReLU(x) (theta [1, L, F]) or ReLU(x) (theta None) straight from the pre-activations x [B, L, F]:
+    entries = positions with x > theta and x > 0.  `overflow` (device int32 [1]) = 1 when more than `cap` entries exist
+    (the lists are then incomplete and the caller takes the dense regime); `total` holds the true count."""
+    _chk(x)
+    Bn, L, F = x.shape
+    if theta is not None:
+        _chk(theta)
+        assert theta.numel() == L * F
+    s = _empty_lists(Bn, L, F, int(cap), x.device)
+    ws = workspace(lib.clt_sparse_build_workspace_bytes(Bn, L, F), x.device)
+    call("clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, Bn, L, F, s.cap,
+         s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
+         s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
+         ws.data_ptr(), ws.numel(), _stream())
+    s.used_fallback = None
+    s.kth = None
+    return s
+
+
+def read_flag(flag: torch.Tensor) -> int:
+    """Host value of a device int32 flag through a side stream behind an event: work queued on the launch stream after
+    this call's event keeps running while the host waits (the launch queue never drains)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    side, host = _flag_reader(flag.device)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        host.copy_(flag, non_blocking=True)
+    side.synchronize()
+    return int(host)
+
+
 def _empty_lists(Bn, L, F, cap, dev) -> SparseLists:
     s = SparseLists()
     s.B, s.L, s.F, s.cap = Bn, L, F, int(cap)
@@ -931,13 +964,18 @@ def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.
 
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
-                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None):
+                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None, row_term=None):
     """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
     per-entry dots go to `dots2` ([slots, lists2.cap]).  `extra` = (compact gradient [n, d] fp32, map int32 [L*F],
-    compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows."""
+    compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows.
+    `row_term` = (dnorm [L*F], sq [L*F]): adds (dnorm[col] / sqrt(sq[col])) * W[row] to the row's gradient."""
     _chk(W); _chk(coef)
+    rdn, rsq = row_term if row_term is not None else (None, None)
+    if rdn is not None:
+        _chk(rdn); _chk(rsq)
+        assert rdn.numel() >= col0 + W.numel() // W.shape[-1] and rsq.numel() >= rdn.numel()
     ex, exmap, excs = extra if extra is not None else (None, None, None)
     if ex is not None:
         _chk(ex); _chk(exmap, torch.int32)
@@ -956,7 +994,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), _stream())
+         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), _stream())
 
 
 def compact_columns(dead_u8: torch.Tensor):

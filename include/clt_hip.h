@@ -233,6 +233,14 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
                          float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                          uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace, size_t ws_bytes,
                          void* stream);
+/* The same lists straight from the pre-activations x [B][L][F] of a thresholding sparsifier — JumpReLU (theta [L*F],
+ * jumprelu.py:33-37: entries = positions with x > theta and x > 0, value x) or ReLU (theta == NULL: x > 0) — without a
+ * dense feature tensor.  When more than `cap` entries exist, overflow[0] = 1 and the lists are incomplete: `cap` is the
+ * caller's break-even between the list regime and the dense GEMM regime (total[0] always holds the true count). */
+int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+                                   int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
+                                   int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
+                                   size_t ws_bytes, void* stream);
 /* Selection straight to lists (replaces topk.py:58-61, 84-91, 117-128 + the list build above when the dense
  * feature tensor is not needed).  mode 0: k of F per (b,l) row (k <= 2048); 1: global k*B*L; 2: per layer k*B.
  * x: [B][L][F] fp32 pre-activations; col_mask (optional, uint8 [L*F]): positions with mask 0 count as -inf
@@ -327,14 +335,16 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  * src_bf16 != 0 (bf16 mode: halves the gather traffic; products still accumulate in fp32).
  * extra (optional, with extra_map): a dense gradient contribution for a subset of the rows — the compacted TopK-aux
  * pass below —: grad[r,:] += extra[extra_map[col0 + r]][0:d] and colsum_out[col] += extra_colsum[extra_map[col]]
- * wherever extra_map[...] >= 0. */
+ * wherever extra_map[...] >= 0.  row_dnorm / row_sq (optional, [L*F], indexed by column): grad[r,:] +=
+ * (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:], the gradient through dec_norms (clt_lightning.py:438-448). */
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
                             const float* coef2, const float* src2, float* dot_out, float* dot_out2, long dot_stride,
                             long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
-                            const int32_t* extra_map, const float* extra_colsum, void* stream);
+                            const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
+                            void* stream);
 /* Column compaction for the TopK-aux pass (clt_lightning.py:539-553: top k_aux among the DEAD features, second decoder
  * pass): the dead columns are gathered so that the pass runs as a dense sub-problem of n_pad columns per layer.
  *   clt_compact_columns: counts[l] = number of dead features of layer l; when idx != NULL also

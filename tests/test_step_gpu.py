@@ -13,15 +13,21 @@ def _opt_and_sched(mod):
     return mod.attach_optimizers()
 
 
-@pytest.mark.parametrize("fused", ["training_step", False, True, "dense", "compact", "compact-grads"],
+@pytest.mark.parametrize("fused", ["training_step", False, True, "dense", "compact", "compact-grads", "lists", "lists-grads"],
                          ids=["training_step", "autograd-loop", "fused-step", "fused-dense-gemm", "fused-step-compact-aux",
-                              "compact-aux-grads"])
+                              "compact-aux-grads", "threshold-lists", "threshold-lists-grads"])
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_training_matches_reference(name, fused, golden, monkeypatch):
     """Modes: "training_step" = the Lightning-facing contract alone (manual optimisation: forward + backward + Adam
     inside training_step, with the optimizer / scheduler objects of configure_optimizers()); "autograd-loop" =
-    fused_step=False under the automatic-optimisation order; the others call fused_train_step with options."""
+    fused_step=False under the automatic-optimisation order; the others call fused_train_step with options.
+    "threshold-lists": JumpReLU / ReLU forced into the activation-list regime (sparse=True: decoder forward by row
+    gather, decoder weight gradient + dec_norms term + Adam in the fused row pass); "-grads": the same with
+    materialised gradients."""
     from tests.build_cases import build_module
+    lists = isinstance(fused, str) and fused.startswith("lists")
+    if lists and name not in ("dbg_jumprelu_clt", "jumprelu_plt_notanh", "relu_clt_base"):
+        pytest.skip("thresholding sparsifiers only")
     compact = isinstance(fused, str) and fused.startswith("compact")
     if compact:
         # the TopK-aux pass as a dense sub-problem on the compacted dead columns (engine.COMPACT_AUX): forced here —
@@ -44,6 +50,11 @@ def test_training_matches_reference(name, fused, golden, monkeypatch):
             loss = mod.training_step(batch, t)
             assert not loss.requires_grad
             grads = {k: mod.last_step["grads"][k].reshape(p.shape) for k, p in params.items() if k in mod.last_step["grads"]}
+        elif lists:
+            loss = mod.fused_train_step(batch, t, opt, sched, fuse_adam=(fused == "lists"), sparse=True)
+            assert mod.last_step.get("lists") is not None
+            grads = {k: mod.last_step["grads"][k].reshape(p.shape) for k, p in params.items() if k in mod.last_step["grads"]}
+            assert (fused == "lists") != any(k.startswith("decoder.W") for k in grads)
         elif fused == "dense":                      # TopK family through the dense MFMA GEMM regime
             loss = mod.fused_train_step(batch, t, opt, sched, fuse_adam=False, sparse=False)
             grads = {k: mod.last_step["grads"][k].reshape(p.shape) for k, p in params.items()}
@@ -377,3 +388,95 @@ def test_logging_side_outputs_match_reference(name, fused, golden):
     stats = df.compute()
     for k, want in gm["dead_features"].items():
         assert torch.allclose(stats[k].float().cpu(), want.float(), rtol=1e-6, atol=0), k
+
+
+def _threshold_case(dec_kind, nl_kind, theta, B=512, L=3, d=128, F=512, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L, d, generator=g)
+    y = 0.5 * x * torch.randn(L, d, generator=g) + 0.1 * torch.randn(B, L, d, generator=g)
+    batch = torch.stack([x, y], 1)
+    nl = {"kind": "relu"} if nl_kind == "relu" else {"kind": "jumprelu", "theta": theta, "bandwidth": 0.1}
+    lc = {"kind": "jumprelu", "lambda_sparsity": 0.05, "c_sparsity": 1.0, "use_tanh": True, "pre_actv_loss": 1e-3}
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.randn(L, F, generator=g) * 0.01,
+              "decoder.b": torch.randn(L, d, generator=g) * 0.01}
+    bd = (d * L) ** -0.5
+    if dec_kind == "clt":
+        for l in range(L):
+            params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * bd
+    else:
+        params["decoder.W"] = (torch.rand(L, F, d, generator=g) * 2 - 1) * bd
+    if nl_kind == "jumprelu":
+        params["nonlinearity.theta"] = torch.full((1, L, F), theta)
+    cfg = {"decoder": dec_kind, "d_features": F, "nonlinearity": nl, "loss": lc}
+    return {"cfg": cfg, "opt": {"lr": 1e-3}, "batches": batch[None], "init_params": params,
+            "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+
+
+@pytest.mark.parametrize("dec_kind,nl_kind", [("clt", "jumprelu"), ("plt", "jumprelu"), ("clt", "relu")])
+def test_threshold_lists_bf16_step(dec_kind, nl_kind):
+    """JumpReLU / ReLU in the activation-list regime, bf16 mode, at shapes that take the fast GEMM kernels: loss and
+    every gradient vs the oracle with the same operand rounding (rtol 2e-2 / relative l2), and — Adam fused into the row
+    pass — the first-step moments vs oracle.adam_step on the list regime's own materialised gradients."""
+    from crosslayer_transcoder_amd import precision
+    from oracle import clt_oracle as O
+    from tests.build_cases import build_module
+    case = _threshold_case(dec_kind, nl_kind, 0.6)          # pre ~ N(0, 0.29^2): about 2 % (JumpReLU) / 50 % (ReLU) active
+    batch = case["batches"][0]
+    mod = build_module(case)
+    mod.global_step, mod.log_metrics_every = 5, 0
+    with precision("bf16-mixed"):
+        out = mod.compute_step(batch.cuda(), 0, sparse=True)
+    assert out.get("lists") is not None
+    if nl_kind == "jumprelu":
+        assert 0 < int(out["lists"].total) < 0.05 * batch.shape[0] * 3 * 512
+    c = dict(case["cfg"]); c["loss"] = dict(c["loss"], step_frac=0.5)
+    buf = {"last_active": case["last_active0"].clone()}
+    with O.operand_rounding(torch.bfloat16):
+        ref = O.training_step(batch, case["init_params"], O.standardizer_init(batch), c, buf)
+    assert_close(out["loss"], ref["loss"], 2e-3, 1e-6, "loss")
+    assert torch.equal(out["features"].cpu() > 0, ref["features"] > 0) or \
+        float(((out["features"].cpu() > 0) != (ref["features"] > 0)).float().mean()) < 1e-4      # bf16 ulps at the threshold
+    for k, gref in ref["grads"].items():
+        gg = out["grads"][k].reshape(gref.shape).cpu()
+        rel = (gg - gref).norm() / (gref.norm() + 1e-12)
+        assert rel < 2e-2, f"{dec_kind}/{nl_kind} lists bf16 grad {k}: rel l2 err {rel:.3g}"
+    # fused: same gradients must arrive in the moments (exp_avg = (1 - beta1) * g after the first step)
+    mod2 = build_module(case)
+    mod2.global_step, mod2.log_metrics_every = 5, 0
+    opt, _ = mod2.attach_optimizers()
+    with precision("bf16-mixed"):
+        mod2.fused_train_step(batch.cuda(), 0, opt, sparse=True)
+    # (with Adam fused the gather forward reads the bf16 shadow rows instead of the fp32 rows: the reconstruction moves
+    # by bf16 rounding of the weights, hence a relative-l2 comparison)
+    for k, p in mod2.model.named_parameters():
+        g = out["grads"][k].reshape(p.shape).double()
+        m = opt.state[p]["exp_avg"].double()
+        rel = float((m - 0.1 * g).norm() / (0.1 * g.norm() + 1e-30))
+        assert rel < 1e-2, f"fused exp_avg {k}: rel l2 {rel:.3g}"
+
+
+def test_threshold_list_gate_chooses_the_regime():
+    """sparse=None on a JumpReLU module: the device-side count picks the list regime below the break-even density and the
+    dense GEMM regime above it (then backs off: no attempt on the next steps); both give the same step (fp32 mode)."""
+    from crosslayer_transcoder_amd import engine
+    from tests.build_cases import build_module
+    for theta, want_lists in ((0.9, True), (0.0, False)):
+        case = _threshold_case("clt", "jumprelu", theta)
+        batch = case["batches"][0].cuda()
+        mod = build_module(case)
+        mod.global_step, mod.log_metrics_every = 5, 0
+        dense0 = engine.STATS.get("list_gate_dense", 0)
+        out = mod.compute_step(batch, 0)
+        density = float((out["features"] > 0).float().mean())
+        assert (out.get("lists") is not None) == want_lists, f"theta {theta}: density {density:.4f}"
+        assert (density <= engine.LIST_MAX_DENSITY) == want_lists
+        if not want_lists:
+            assert engine.STATS["list_gate_dense"] == dense0 + 1 and mod._list_skip >= engine.LIST_RETRY_FIRST
+            mod.compute_step(batch, 1)
+            assert engine.STATS["list_gate_dense"] == dense0 + 1      # backed off: no second attempt
+        ref = build_module(case)
+        ref.global_step, ref.log_metrics_every = 5, 0
+        out2 = ref.compute_step(batch, 0, sparse=not want_lists) if want_lists else ref.compute_step(batch, 0, sparse=True)
+        assert_close(out["loss"], out2["loss"], 1e-5, 1e-8, "loss: list regime vs dense regime")
+        for k, g2 in out2["grads"].items():
+            assert_close(out["grads"][k].reshape(g2.shape), g2, 1e-4, 2e-6 * float(g2.abs().max()) + 1e-12, f"grad {k}")
