@@ -43,6 +43,7 @@ SIGNATURES = {
     "clt_mse_f32": (I, [P, P, L, P, P, I, I, F32, P, P, P, P, SZ, P]),
     "clt_mse_bf16_colsum_workspace_bytes": (SZ, [I, I]),
     "clt_mse_bf16_colsum_f32": (I, [P, P, L, P, P, I, I, F32, P, P, I, P, P, SZ, P]),
+    "clt_mse_bf16_colsum_layers_f32": (I, [P, P, L, P, P, I, I, I, F32, P, P, I, P, P, SZ, P]),
     "clt_mse_bf16_colsum_noalloc_max_bytes": (SZ, []),
     "clt_mse_bf16_colsum_noalloc_f32": (I, [P, P, L, P, P, I, I, F32, P, P, I, P, P]),
     "clt_aux_mse_f32": (I, [P, P, P, L, F32, P, P, P, P, SZ, P]),
@@ -76,7 +77,7 @@ SIGNATURES = {
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,
                                      P, P, SZ, P]),
-    "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, P]),
+    "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P, P, P]),
     "clt_compact_columns": (I, [P, I, I, I, P, P, P, P]),

@@ -171,13 +171,17 @@ constexpr int MF_R = 64;
 __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
                                                               const float* __restrict__ mean, const float* __restrict__ stdv, int rows,
                                                               int n, float gs, uint16_t* __restrict__ g16, float* __restrict__ part_c,
-                                                              double* __restrict__ part_l) {
+                                                              double* __restrict__ part_l, int layer_rows) {
     __shared__ float red[4][256];
     __shared__ double sh[4];
     const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = blockIdx.x * 256 + 4 * tx;
     const int r0 = blockIdx.y * MF_R;
     const bool cin = col < n;
+    // layer_rows > 0: r / g16 rows are layer-major (row = layer * layer_rows + token, layer_rows % 64 == 0, so a block's
+    // rows share one layer); the target row of (layer, token) is y + token * yrs + layer * n and mean / std are [layers][n]
+    const int layer = layer_rows > 0 ? r0 / layer_rows : 0;
+    if (layer_rows > 0) { y += (long)layer * n - (long)layer * layer_rows * yrs; mean += (long)layer * n; stdv += (long)layer * n; }
     float4 mu = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sd = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (cin) { mu = *reinterpret_cast<const float4*>(mean + col); sd = *reinterpret_cast<const float4*>(stdv + col); }
     float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -204,10 +208,12 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < n) part_c[(long)blockIdx.y * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// out[c] (+)= sum over chunks of part[chunk][c], fixed order
+// out[g][c] (+)= sum over the chunks of group g (blockIdx.y; nchunks consecutive chunks each) of part[chunk][c], fixed order
 __global__ void sum_chunks_kernel(const float* __restrict__ part, int nchunks, int n, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
+    part += (long)blockIdx.y * nchunks * n;
+    out += (long)blockIdx.y * n;
     float s = 0.0f;
     for (int k = 0; k < nchunks; ++k) s += part[(long)k * n + c];
     out[c] = accumulate ? out[c] + s : s;
@@ -716,9 +722,11 @@ size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n) {
     const size_t chunks = (size_t)(rows + MF_R - 1) / MF_R, ctiles = (size_t)(n + 255) / 256;
     return chunks * ctiles * sizeof(double) + chunks * (size_t)n * sizeof(float);
 }
-int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n, float gs,
-                            uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* ws, size_t wsb, void* st) {
+static int mse_bf16_colsum_impl(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n, float gs,
+                                uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* ws, size_t wsb, void* st,
+                                int layer_rows) {
     if (rows <= 0 || n <= 0 || yrs < n || !g16 || !colsum || !loss_sum) return CLT_ERR_SHAPE;
+    if (layer_rows < 0 || (layer_rows > 0 && (layer_rows % MF_R || rows % layer_rows))) return CLT_ERR_SHAPE;
     if (n % 4 || yrs % 4 || !aligned16(r) || !aligned16(y) || !aligned16(mean) || !aligned16(stdv) || (reinterpret_cast<uintptr_t>(g16) & 7))
         return CLT_ERR_ALIGN;
     if (!ws || wsb < clt_mse_bf16_colsum_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
@@ -726,10 +734,25 @@ int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const floa
     double* part_l = (double*)ws;
     float* part_c = (float*)(part_l + (size_t)chunks * ctiles);
     hipLaunchKernelGGL(mse_bf16_colsum_kernel, dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
-                       part_c, part_l);
+                       part_c, part_l, layer_rows);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)part_l, chunks * ctiles, 1, loss_sum);
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(st), (const float*)part_c, chunks, n, colsum, accumulate);
+    const int groups = layer_rows > 0 ? rows / layer_rows : 1;        // column sums per layer: colsum is [layers][n]
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256, groups), dim3(256), 0, as_stream(st), (const float*)part_c, chunks / groups, n,
+                       colsum, accumulate);
     CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n, float gs,
+                            uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* ws, size_t wsb, void* st) {
+    return mse_bf16_colsum_impl(r, y, yrs, mean, stdv, rows, n, gs, g16, colsum, accumulate, loss_sum, ws, wsb, st, 0);
+}
+// The same pass over a layer-major slab: r / g16 are [layers][layer_rows][n] (rows = layers * layer_rows, layer_rows % 64 == 0),
+// the target row of (layer, token) is y + token * y_row_stride + layer * n (the [B][2][L][d] batch), mean / std / colsum are
+// [layers][n].  One launch per group of layers of the feature-sharded step's pipelined exchange.
+int clt_mse_bf16_colsum_layers_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,
+                                   int layer_rows, float gs, uint16_t* g16, float* colsum, int accumulate, double* loss_sum, void* ws,
+                                   size_t wsb, void* st) {
+    if (layer_rows <= 0) return CLT_ERR_SHAPE;
+    return mse_bf16_colsum_impl(r, y, yrs, mean, stdv, rows, n, gs, g16, colsum, accumulate, loss_sum, ws, wsb, st, layer_rows);
 }
 // ---- clt_mse_bf16_colsum_noalloc_f32: the same pass for callers that cannot allocate ------------------------------------
 // The partial sums of clt_mse_bf16_colsum_f32 (per-block loss partials + per-row-chunk column partials) live in a

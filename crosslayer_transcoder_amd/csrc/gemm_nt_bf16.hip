@@ -17,6 +17,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef GEMM_VARIANT
+#define GEMM_VARIANT 0
+#endif
+
 namespace {
 constexpr int TB = 256, TA = 256, TK = 64;              // tile: B rows (C columns), A rows (C rows), k
 constexpr int OP_BYTES = 256 * TK * 2;                  // one operand tile in LDS (32 KiB)
@@ -137,6 +141,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i] | oob, kt * (TK * 2), 0, 0);
     };
 
+    // one DMA piece of a k-tile: q = 0..3 B pieces, 4..7 A pieces (so that the issue can be spread between MFMA groups)
+    auto stage_piece = [&](int buf, int kt, int q) {
+        unsigned char* base = nt_smem + buf * STAGE_BYTES;
+        const int oob = kt == nk - 1 ? tail_oob : 0;
+        const int i = q & 3;
+        if (q < 4) {
+            int sob = kt * (TK * 2);
+            __amdgpu_buffer_rsrc_t rb = rB;
+            if (EPI == 0 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i] | oob, kt * (TK * 2), 0, 0);
+        }
+    };
+
     // The tile's bias slice rides along as a ninth DMA piece of wave 0 (columns past N read as zero through the
     // descriptor's bound): the epilogues then read it from LDS, so no global load is pending anywhere near the stores —
     // a pending load makes the compiler put a full vmcnt(0) in front of every store of the epilogue.
@@ -210,16 +229,28 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         if (r == 16) {
                             if (diag & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (ablation: no wait for the DMA — wrong results)
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if GEMM_VARIANT == 0
                             if (kt + 2 < nk) stage(kt & 1, kt + 2);
+#endif
 #pragma unroll
                             for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nbase, 0, n);
                         }
                         fb[r & 7] = ldB(nbase, 0, r & 7);
+#if GEMM_VARIANT == 1 || GEMM_VARIANT == 2
+                        // the restage of the buffer just freed, two DMA pieces per MFMA group (groups 12..15)
+                        if (kt + 2 < nk) { stage_piece(kt & 1, kt + 2, (r - 16) * 2); stage_piece(kt & 1, kt + 2, (r - 16) * 2 + 1); }
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#if GEMM_VARIANT == 2
+                    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[ks][n], acc[m][n], 0, 0, 0);
+#if GEMM_VARIANT == 2
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };

@@ -245,6 +245,55 @@ __global__ void merge_gate_kernel(int S, int world, const uint32_t* __restrict__
     }
 }
 
+// ---- exhaustive tie resolution (flag 8): no tie lists ------------------------------------------------------------------
+// When more candidates tie at the k-th value than a tie block holds, the `krem` tied entries with the lowest GLOBAL flat
+// index are found by a radix select on the index itself: four rounds of 8 bits, ascending, each closed by an all-reduce
+// (sum) of the 256-bin histograms over the shards.  After round 3 TieX.prefix is the exact index of the last tied entry
+// that is taken; the emitters then take a tied entry iff its index <= that.  Exact for any number of ties.
+struct TieX { uint32_t prefix, mask, krem, pad; };
+
+__global__ __launch_bounds__(TPB) void tie_hist_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
+                                                       const SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
+                                                       const TieX* __restrict__ tiex, int F, Shard sd, uint32_t* __restrict__ ghist, int round) {
+    __shared__ uint32_t hist[256];
+    const int s = blockIdx.y;
+    const SegState st = state[s];
+    if (!need_rank(st)) return;
+    const TieX t = tiex[s];
+    const int shift = 24 - 8 * round;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = ctl[s].cand_cnt;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        if (cand_key[(size_t)s * capS + i] != st.prefix) continue;
+        const uint32_t gi = global_index(cand_idx[(size_t)s * capS + i], F, sd);
+        if ((gi & t.mask) == t.prefix) atomicAdd(&hist[(gi >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    const uint32_t h = hist[threadIdx.x];
+    if (h) atomicAdd(&ghist[(long)s * NBIN + threadIdx.x], h);
+}
+
+// one wave per segment: consume the all-reduced histogram of round `round` (bins ascending), narrow the index prefix
+__global__ void tie_find_kernel(const SegState* __restrict__ state, TieX* __restrict__ tiex, uint32_t* __restrict__ ghist, int round) {
+    const int s = blockIdx.x;
+    if (!need_rank(state[s])) return;
+    if (threadIdx.x == 0) {
+        TieX t = tiex[s];
+        uint32_t krem = round == 0 ? state[s].krem : t.krem;
+        const int shift = 24 - 8 * round;
+        uint32_t cum = 0;
+        int b = 0;
+        for (; b < 255; ++b) { const uint32_t h = ghist[(long)s * NBIN + b]; if (cum + h >= krem) break; cum += h; }
+        t.prefix |= (uint32_t)b << shift;
+        t.mask |= 255u << shift;
+        t.krem = krem - cum;
+        tiex[s] = t;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) ghist[(long)s * NBIN + i] = 0;
+}
+
 // ---- stage 3: selected, positive candidates -> entry list + per-row / per-column counts -------------
 __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ cand_key, const uint32_t* __restrict__ cand_idx, uint32_t capS,
                                                    const SelCtl* __restrict__ ctl, const SegState* __restrict__ state,
@@ -252,7 +301,7 @@ __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ sel_idx, float* __restrict__ sel_val,
                                                    uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt,
                                                    float* __restrict__ threshold, float e, Head* __restrict__ head,
-                                                   int32_t* __restrict__ overflow) {
+                                                   int32_t* __restrict__ overflow, const TieX* __restrict__ tiex) {
     if (head->gate) return;
     __shared__ uint32_t sh[8];
     __shared__ uint32_t sbase;
@@ -276,6 +325,7 @@ __global__ __launch_bounds__(TPB) void emit_kernel(const uint32_t* __restrict__ 
         if (key < T) return false;
         if (!rank_ties) return true;
         const uint32_t me = global_index(ci[i], F, sd);
+        if (tiex) return me <= tiex[s].prefix;          // exhaustive tie resolution: index bound from the radix select
         uint32_t r = 0;
         for (int q = 0; q < sd.world; ++q) {            // tied entries of every shard, by global index
             const uint32_t* blk = tie_region + q * tie_block_words(S);
@@ -399,6 +449,8 @@ struct SelArgs {
 //                        3 find 1, hist 2                  [SUM ghist]
 //                        4 find 2, ties                    [ALL-GATHER tie blocks]
 //                        5 merge gate, emit, build lists (+ single-GPU exhaustive fallback, gated)
+// With flag 8 (exhaustive tie resolution, sharded): 4 find 2, tie-index hist 0 [SUM ghist]; 5..7 tie find r, tie hist r + 1
+//                        [SUM ghist]; 8 tie find 3, emit, build lists.  No tie lists, no limit on the number of ties.
 // Rows mode runs entirely in stage 5 (no cross-row state).
 int run_stages(const SelArgs& a, int lo, int hi) {
     const int B = a.B, L = a.L, F = a.F, k = a.k, mode = a.mode;
@@ -443,7 +495,9 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     int nbk = (int)((p.capS + TPB * 16 - 1) / (TPB * 16)); if (nbk > 512) nbk = 512; if (nbk < 1) nbk = 1;
     const dim3 cgrid(nbk, p.S);
     const bool split = (a.exhaustive & 4) != 0;
-    const int last_stage = split ? 6 : 5;
+    const bool tie_radix = (a.exhaustive & 8) != 0;        // exact for any number of ties: index radix select, no tie lists
+    const int last_stage = tie_radix ? 8 : (split ? 6 : 5);
+    TieX* tiex = (TieX*)tie_region;                        // (the tie blocks are unused in that form; zeroed in stage 0)
 
     for (int stage = lo; stage <= hi; ++stage) {
         if (stage == 0) {
@@ -480,6 +534,24 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             if (stage == 2) hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, st, ctl, tot, p.S, p.Kseg, p.capS, head);
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, stage - 2, gate, 0);
             hipLaunchKernelGGL(cand_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, p.capS, ctl, state, ghist, stage - 1);
+        } else if (tie_radix && stage >= 4) {
+            if (stage == 4) hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
+            else hipLaunchKernelGGL(tie_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, tiex, ghist, stage - 5);
+            if (stage < 8) {
+                hipLaunchKernelGGL(tie_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tiex, F, a.sd, ghist, stage - 4);
+                continue;
+            }
+            const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
+            const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;
+            hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
+                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, tiex);
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
+                               a.ent_col, a.ent_val);
+            hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
+                               (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
+            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
+                               long_list, &head->long_rows, gate, 0);
         } else if (stage == 4) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
@@ -499,7 +571,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
             const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
             hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
-                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow);
+                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, (const TieX*)nullptr);
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);
@@ -589,11 +661,13 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
                                  float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                                  uint8_t* fired, uint32_t* total, int32_t* overflow, int32_t* used_fallback, void* ws, size_t wsb,
                                  void* stp) {
-    if (stage_lo < 0 || stage_hi > 5 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1) return CLT_ERR_SHAPE;
+    if (stage_lo < 0 || stage_hi > ((exhaustive & 8) ? 8 : 5) || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1)
+        return CLT_ERR_SHAPE;
+    if ((exhaustive & 8) && !(exhaustive & 1)) return CLT_ERR_SHAPE;       // the index radix form runs on exhaustive candidates
     if (f_off < 0 || f_off + F > F_global) return CLT_ERR_SHAPE;
     SelArgs a{x, col_mask, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
               csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
-              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, exhaustive & 1, nullptr, 0.0f};
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, exhaustive & 9, nullptr, 0.0f};
     return run_stages(a, stage_lo, stage_hi);
 }
 

@@ -25,7 +25,8 @@ template <int NT, bool VEC, bool BF>
 __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
                                                                  const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int L, int F,
-                                                                 int d, int cross_layer, uint32_t cap) {
+                                                                 int d, int cross_layer, uint32_t cap, long out_tok_stride,
+                                                                 long out_layer_stride) {
     constexpr int W = VEC ? 4 : 1;
     constexpr int U = NT <= 4 ? 4 : (NT <= 8 ? 2 : 1);         // entries in flight per wave (bounded by the register budget)
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
                 }
             }
         }
-        float* dst = out + ((long)b * L + l) * d;
+        float* dst = out + (long)b * out_tok_stride + (long)l * out_layer_stride;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int o = (t * 64 + lane) * W;
@@ -390,15 +391,16 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,
                                const float* bias, float* out, int B, int L, int F, int d, int cross_layer, uint32_t cap,
-                               int w_bf16, void* stp) {
+                               int w_bf16, long out_tok_stride, long out_layer_stride, void* stp) {
     if (B <= 0 || L <= 0 || F <= 0 || d <= 0) return CLT_ERR_SHAPE;
-    const bool vec = d % 4 == 0 && aligned16(out);
+    if (out_tok_stride == 0 && out_layer_stride == 0) { out_tok_stride = (long)L * d; out_layer_stride = d; }   // [B][L][d]
+    const bool vec = d % 4 == 0 && aligned16(out) && out_tok_stride % 4 == 0 && out_layer_stride % 4 == 0;
 #define FWDK(NT_, VEC_)                                                                                              \
     do {                                                                                                              \
         if (w_bf16) hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true>), dim3(B), dim3(TPB), 0, as_stream(stp),  \
-                                       row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap);      \
+                                       row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
         else hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, false>), dim3(B), dim3(TPB), 0, as_stream(stp), \
-                                row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap);             \
+                                row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
     } while (0)
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);
     if (vec) {

@@ -101,6 +101,11 @@ FUSE_DENSE_JUMPRELU = True
 FUSE_WEIGHT_PREP = True
 #: list regime, bf16 mode, base loss: loss sum + bf16 gradient rows + decoder bias gradient in one pass over the error
 FUSE_MSE_BF16 = True
+#: feature-sharded list regime, cross-layer decoder, base loss: the partial reconstruction is written layer-major and
+#: exchanged as L per-layer all-reduces issued at once on RCCL's stream; the loss of layer l and the weight pass of W_l
+#: (which gathers only g[:, l, :]) start as soon as slab l has arrived, so the exchange of the other layers runs under
+#: them instead of in front of the whole backward pass
+PIPELINE_EXCHANGE = True
 #: thresholding sparsifiers (JumpReLU / ReLU): break-even between the activation-list regime and the dense GEMM regime as
 #: a share of the B*L*F entries that are active (L0 / F).  Below it the decoder forward is a row gather and the decoder
 #: weight gradient + Adam one fused row pass; above it (e.g. an untrained JumpReLU at theta = 0.03: ~45 % active) the
@@ -305,20 +310,25 @@ class _Decoder:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
             ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
 
-    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None):
+    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None, slabs=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
         Returns (dval [S.cap], dval2 [S2.cap] or None).  extra = ({name: compact dW}, map): dense gradient of the
-        compacted aux pass, added to the mapped rows."""
+        compacted aux pass, added to the mapped rows.  slabs (cross-layer decoder, pipelined exchange): slabs(l) returns
+        layer l's gradient slab [B, d] once it can be computed; the matrices are then walked from the last layer down."""
         dev = S.csc_val.device
         slots = self.L if self.clt else 1
         dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
         dots2 = torch.empty(slots, S2.cap, dtype=torch.float32, device=dev) if S2 is not None else None
-        if self.bf16:                      # bf16 mode: gathered g rows as bf16 (fp32 accumulate), half the gather bytes
+        if self.bf16 and slabs is None:    # bf16 mode: gathered g rows as bf16 (fp32 accumulate), half the gather bytes
             g = g16 if g16 is not None else ops.cast_bf16(g)      # (g16: the loss kernel already wrote the bf16 rows)
             g2 = ops.cast_bf16(g2) if g2 is not None else None
         second = (S2, S2.csc_val, g2) if S2 is not None else None
-        for l, (name, w) in enumerate(zip(self.names(), self.W32)):
+        todo = list(enumerate(zip(self.names(), self.W32)))
+        for l, (name, w) in (reversed(todo) if slabs is not None else todo):
             kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
+            if slabs is not None:
+                g = slabs(l)
+                kw["src_slab"] = True
             if extra is not None:
                 kw["extra"] = (extra[0][name].view(-1, w.shape[-1]), extra[1], None)
             if fused is not None:
@@ -351,6 +361,20 @@ def _threshold_lists(mod, pre, theta, force: bool):
         return None
     mod._list_retry = LIST_RETRY_FIRST // 2
     return S
+
+
+def _exchange_groups(L):
+    """Layer groups of the pipelined exchange, last layers first, as (lo, hi) ranges: sizes 1, 2, 3, rest — the first group
+    is small (its all-reduce is the only one nothing can hide) and every later group's all-reduce runs under the weight
+    passes of the groups before it (W_l costs (l + 1) / sum of the work)."""
+    out, hi = [], L
+    for size in (1, 2, 3, L):
+        if hi <= 0:
+            break
+        lo = max(0, hi - size)
+        out.append((lo, hi))
+        hi = lo
+    return out
 
 
 def _list_capacity(nl, Bn, L, F):
@@ -450,37 +474,90 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"
 
+    lists_only = sparse and kind != "jumprelu"           # every gradient comes from the lists (TopK family; ReLU + base loss)
+    pipelined = bool(PIPELINE_EXCHANGE and shard is not None and lists_only and kind == "base" and D.clt)
+    waits = None
     if sparse:
-        r = D.sparse_fwd(S)
         fired = S.fired
     elif fused_ops is not None:
-        r = D.fwd(None, feat_op=fused_ops[0])
         fired = fused_ops[2]
     else:
-        r = D.fwd(feat)
         fired = ops.column_any_positive(feat)
-    g16 = b_grad = None
-    lists_only = sparse and kind != "jumprelu"           # every gradient comes from the lists (TopK family; ReLU + base loss)
-    fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and lists_only and bf16 and kind == "base") else None
-    if fm is not None:                       # loss + bf16 gradient rows + decoder bias gradient in one pass, no fp32 gradient
+
+    def dead_features():
+        dd, cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
+        if shard is not None:                 # features are split over ranks: count over all shards
+            cnt = shard.all_reduce_sum(cnt.clone())
+        return dd, cnt
+
+    if pipelined:
+        # partial reconstruction layer-major [L, B, d].  Launched first (the host has just read the selection's outcome flag
+        # and the launch queue is empty); the dead-feature update and its tiny all-reduce follow, and only then are the
+        # all-reduces of the layer groups queued on RCCL's stream — no small collective waits behind them
+        r_lm = ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True, w_bf16=D.shadow, layer_major=True)
+        dead, dead_cnt = dead_features()
+        groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
+        waits = [shard.all_reduce_sum_async(r_lm[lo:hi]) for lo, hi in groups]
+        r = None
+    else:
+        if sparse:
+            r = D.sparse_fwd(S)
+        elif fused_ops is not None:
+            r = D.fwd(None, feat_op=fused_ops[0])
+        else:
+            r = D.fwd(feat)
+        dead, dead_cnt = dead_features()
+    g16 = b_grad = slabs = None
+    fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and lists_only and bf16 and kind == "base"
+                                                                 and not pipelined) else None
+    if pipelined:
+        # per layer, once its slab has been reduced: loss partial + gradient slab (+ bias-gradient row); called by the
+        # backward pass right before the weight pass of W_l
+        g = ys = None
+        loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
+        b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
+        g_lm = torch.empty(L, Bn, d, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+
+        group_of = {l: gi for gi, (lo, hi) in enumerate(groups) for l in range(lo, hi)}
+        done = set()
+
+        def slabs(l):
+            gi = group_of[l]
+            if gi not in done:                           # first layer of its group: wait for the group's all-reduce, then its loss
+                done.add(gi)
+                waits[gi]()                              # (the current stream waits; the host does not)
+                lo, hi = groups[gi]
+                if not (bf16 and ops.mse_bf16_colsum_layers(r_lm[lo:hi], mlp_out[:, lo:hi], ost.mean[lo:hi], ost.std[lo:hi], N,
+                                                            g_lm[lo:hi], b_grad[lo:hi], loss_parts[gi:gi + 1])):
+                    for ll in range(lo, hi):             # generic form, layer by layer (fp32 mode, odd shapes)
+                        ls, gl, _ = ops.mse(r_lm[ll], mlp_out[:, ll], ost.mean[ll], ost.std[ll], True, False, count=N)
+                        loss_parts[gi:gi + 1].add_(ls)
+                        ops.column_sum(gl, b_grad[ll])
+                        g_lm[ll].copy_(ops.cast_bf16(gl) if bf16 else gl)
+            return g_lm[l]
+        terms = {}
+    elif fm is not None:                     # loss + bf16 gradient rows + decoder bias gradient in one pass, no fp32 gradient
         loss_sum, g16, b_grad = fm
         g = ys = None
+        terms = {"mse": (loss_sum[0] / N).float()}
     else:
         loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
-    terms = {"mse": (loss_sum[0] / N).float()}
-    dead, dead_cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
-    if shard is not None:                     # features are split over ranks: count over all shards
-        dead_cnt = shard.all_reduce_sum(dead_cnt.clone())
+        terms = {"mse": (loss_sum[0] / N).float()}
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
-    out = StepOutput(terms=terms, grads=grads, dead=dead, recons_norm=r)
+    out = StepOutput(terms=terms, grads=grads, dead=dead)
+    out.lazy = {}
+    if pipelined:
+        out.lazy["recons_norm"] = lambda: r_lm.permute(1, 0, 2).contiguous()
+    else:
+        out["recons_norm"] = r
     if pre is not None:
         out["pre_actvs"] = pre
     else:
-        out.lazy = {"pre_actvs": lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)}
+        out.lazy["pre_actvs"] = lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     if feat is not None:
         out["features"] = feat
     elif fused_ops is not None:
-        out.lazy = {"features": (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))}
+        out.lazy["features"] = (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))
 
     if lists_only:
         S2 = g_aux = cx = None
@@ -519,10 +596,10 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
             grads["decoder.b"] = ops.column_sum(g_aux)
         else:
-            loss = terms["mse"]
+            loss = terms.get("mse")              # (pipelined exchange: known after the backward pass)
         if b_grad is not None:
             grads["decoder.b"] = b_grad
-        else:
+        elif not pipelined:
             grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
         xsrc = xs16 if bf16 else xs32
         extra_dec = extra_enc = None
@@ -538,7 +615,11 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                 dWt_c = ops.encoder_wgrad(xs32, dpre_c)
             extra_dec = (gc, cmap)
             extra_enc = (dWt_c.view(-1, d), cmap, ops.column_sum(dpre_c).view(-1))
-        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16)
+        dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
+                                   slabs=slabs)
+        if pipelined:
+            terms["mse"] = (loss_parts.sum() / N).float()
+            loss = terms["mse"]
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
         db = torch.empty(L, F, dtype=torch.float32, device=dev)

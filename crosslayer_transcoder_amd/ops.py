@@ -468,8 +468,9 @@ def mask_dead(x, dead_u8):
 
 
 # ----------------------------------------------------------------------------------------- K8 - K12
-def mse(r, y, mean, std, want_grad=True, want_ys=False):
-    """Returns (loss_sum fp64 [1], g or None, ys or None); g = 2/(B*L*d) * (r - ys)."""
+def mse(r, y, mean, std, want_grad=True, want_ys=False, count: Optional[int] = None):
+    """Returns (loss_sum fp64 [1], g or None, ys or None); g = 2/count * (r - ys), count = number of elements of the
+    whole reconstruction (default: of r; a caller that passes one layer's slab gives B*L*d)."""
     _chk(r); _chk(y, contiguous=False); _chk(mean); _chk(std)
     rows, n, rs = _rows_view(y)
     g = torch.empty_like(r) if want_grad else None
@@ -477,26 +478,46 @@ def mse(r, y, mean, std, want_grad=True, want_ys=False):
     loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
     nb = lib.clt_reduce_workspace_bytes(rows * n)
     ws = workspace(nb, r.device)
-    call("clt_mse_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (rows * n),
+    call("clt_mse_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (count or rows * n),
          g.data_ptr() if want_grad else None, ys.data_ptr() if want_ys else None, loss_sum.data_ptr(), ws.data_ptr(),
          ws.numel(), _stream())
     return loss_sum, g, ys
 
 
-def mse_bf16_colsum(r, y, mean, std):
-    """Base loss of the list regime in bf16 mode, one pass: (loss_sum fp64 [1], g16 = bf16 2/(B*L*d) * (r - ys),
-    column sums of that gradient in fp32 = the decoder bias gradient).  None when the layout does not qualify."""
+def mse_bf16_colsum(r, y, mean, std, count: Optional[int] = None, g16=None, colsum=None):
+    """Base loss of the list regime in bf16 mode, one pass: (loss_sum fp64 [1], g16 = bf16 2/count * (r - ys),
+    column sums of that gradient in fp32 = the decoder bias gradient).  count: see mse().  g16 / colsum: preallocated
+    outputs (slab views).  None when the layout does not qualify."""
     _chk(r); _chk(y, contiguous=False); _chk(mean); _chk(std)
     rows, n, rs = _rows_view(y)
-    if n % 4 or rs % 4 or y.data_ptr() % 16:
+    if n % 4 or rs % 4 or y.data_ptr() % 16 or r.data_ptr() % 16 or mean.data_ptr() % 16 or std.data_ptr() % 16:
         return None
-    g16 = torch.empty(r.shape, dtype=torch.bfloat16, device=r.device)
-    colsum = torch.empty(mean.shape, dtype=torch.float32, device=r.device)
+    if g16 is None:
+        g16 = torch.empty(r.shape, dtype=torch.bfloat16, device=r.device)
+    if colsum is None:
+        colsum = torch.empty(mean.shape, dtype=torch.float32, device=r.device)
+    _chk(g16, torch.bfloat16); _chk(colsum)
     loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
     ws = workspace(lib.clt_mse_bf16_colsum_workspace_bytes(rows, n), r.device)
-    call("clt_mse_bf16_colsum_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (rows * n),
+    call("clt_mse_bf16_colsum_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (count or rows * n),
          g16.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return loss_sum, g16, colsum
+
+
+def mse_bf16_colsum_layers(r_lm, y, mean, std, count: int, g16_lm, colsum, loss_sum):
+    """mse_bf16_colsum over a group of layers of a layer-major reconstruction: r_lm / g16_lm [nl, B, d] (contiguous slices of
+    the [L, B, d] tensors), y = batch[:, 1, lo:lo + nl] ([B, nl, d] view), mean / std / colsum [nl, d], loss_sum fp64 [1]
+    (all preallocated views).  False when the layout does not qualify (B % 64, d % 4, alignment)."""
+    _chk(r_lm); _chk(g16_lm, torch.bfloat16); _chk(mean); _chk(std); _chk(colsum); _chk(y, contiguous=False)
+    nl, Bn, d = r_lm.shape
+    rs = y.stride(0)
+    if (Bn % 64 or d % 4 or rs % 4 or y.stride(1) != d or y.stride(2) != 1 or any(t.data_ptr() % 16 for t in (r_lm, y, mean, std))
+            or g16_lm.data_ptr() % 8):
+        return False
+    ws = workspace(lib.clt_mse_bf16_colsum_workspace_bytes(nl * Bn, d), r_lm.device)
+    call("clt_mse_bf16_colsum_layers_f32", r_lm.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), nl * Bn, d, Bn,
+         2.0 / count, g16_lm.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return True
 
 
 def aux_mse(aux_r, ys, r, g_main, scale: float):
@@ -658,7 +679,7 @@ def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wei
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
     __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
-                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth")
+                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth", "tie_radix")
 
 
 def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
@@ -813,7 +834,7 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
         if k == 0:
             stages(0, 5)
             break
-        run_sharded_selection(stages, shard, S, exchange)
+        run_sharded_selection(stages, shard, S, exchange, tie_radix=bool(exhaustive & 8))
         outcome = int(fb)                          # host read of the gate every rank agrees on (it rides in the tie gather)
         if outcome & 2 and cap < kglob:
             # a shard holding far more than its share of the selection would overflow its list capacity: redo the
@@ -821,11 +842,16 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
             attempts.insert(0, (exhaustive, kglob))
             continue
         if outcome != 0:                           # not every rank had enough candidates (or too many exact ties)
+            if exhaustive & 8:
+                raise CltError("clt_select_lists_sharded_f32", outcome)      # (cannot happen: this form has no capacity limits)
             if exhaustive:
-                raise NotImplementedError("BatchTopK under feature sharding: more than 4096 values tied at the threshold on one shard")
+                # more entries tied at the k-th value than a tie block holds (4096 per shard and segment): the form that
+                # resolves ties by a radix select on the global index — four more small all-reduces, any number of ties
+                attempts.append((9, kglob))
             continue
         break
     s.used_fallback = torch.full((1,), exhaustive, dtype=torch.int32, device=x.device)
+    s.tie_radix = bool(exhaustive & 8)
     s.kth = None
     if k > 0:
         o6 = lib.clt_select_lists_exchange_info(*dims, 6)
@@ -954,23 +980,27 @@ def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
 
 
 def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool,
-                       w_bf16: bool = False):
-    """wptr: device table of per-target-layer weight pointers (fp32 rows, or bf16 shadow rows when w_bf16)."""
-    out = torch.empty(s.B, s.L, d, dtype=torch.float32, device=wptr.device)
+                       w_bf16: bool = False, layer_major: bool = False):
+    """wptr: device table of per-target-layer weight pointers (fp32 rows, or bf16 shadow rows when w_bf16).
+    layer_major: the result as [L, B, d] (every layer's slab contiguous) instead of [B, L, d]."""
+    out = torch.empty((s.L, s.B, d) if layer_major else (s.B, s.L, d), dtype=torch.float32, device=wptr.device)
+    ts, ls = (d, s.B * d) if layer_major else (s.L * d, d)
     call("clt_sparse_decoder_fwd_f32", s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(),
          wptr.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), s.B, s.L, s.F, d,
-         int(cross_layer), s.cap, int(w_bf16), _stream())
+         int(cross_layer), s.cap, int(w_bf16), ts, ls, _stream())
     return out
 
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
-                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None, row_term=None):
+                    shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None, row_term=None,
+                    src_slab=False):
     """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
     per-entry dots go to `dots2` ([slots, lists2.cap]).  `extra` = (compact gradient [n, d] fp32, map int32 [L*F],
     compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows.
-    `row_term` = (dnorm [L*F], sq [L*F]): adds (dnorm[col] / sqrt(sq[col])) * W[row] to the row's gradient."""
+    `row_term` = (dnorm [L*F], sq [L*F]): adds (dnorm[col] / sqrt(sq[col])) * W[row] to the row's gradient.
+    `src_slab`: `src` is ONE layer's slab [B, d] (layer `src_layer` of a layer-major source) instead of [B, L, d]."""
     _chk(W); _chk(coef)
     rdn, rsq = row_term if row_term is not None else (None, None)
     if rdn is not None:
@@ -986,11 +1016,17 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
     rows = W.numel() // d
     a = adam or dict(lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False, step=1)
     s2, c2, x2 = second if second is not None else (None, None, None)
+    src_ptr, src_L = src.data_ptr(), s.L
+    if src_slab:
+        # the kernel reads src + tok * (L * d) + layer * d: with L = 1 and the base moved back by layer * d elements that
+        # is slab + tok * d (the moved base itself is never dereferenced)
+        assert src_layer >= 0 and second is None and src.shape == (s.B, d)
+        src_ptr, src_L = src.data_ptr() - src_layer * d * src.element_size(), 1
     if x2 is not None and (x2.dtype == torch.bfloat16) != src_bf16:
         raise TypeError("both gather sources must have the same dtype")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4, shadow is not None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, s.L, col0,
-         src_layer, s.col_start.data_ptr(), s.csc_tok.data_ptr(), coef.data_ptr(), src.data_ptr(),
+    _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4, shadow is not None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, src_L, col0,
+         src_layer, s.col_start.data_ptr(), s.csc_tok.data_ptr(), coef.data_ptr(), src_ptr,
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),

@@ -49,6 +49,16 @@ class FeatureShard:
     def all_reduce_sum(self, t):
         return self._run(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group), t)
 
+    def all_reduce_sum_async(self, t):
+        """Starts all-reduce(sum) of `t` in place and returns wait(): RCCL runs it on its own stream behind the work
+        already queued on the current stream; wait() makes the CURRENT STREAM wait for it (the host does not block), so
+        kernels queued in between overlap the exchange.  Host-staged (gloo) groups reduce at once."""
+        if self._host_staged and t.is_cuda:
+            self.all_reduce_sum(t)
+            return lambda: None
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work.wait
+
     def all_reduce_min(self, t):
         return self._run(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.group), t)
 
@@ -80,7 +90,7 @@ class FeatureShard:
         return t.narrow(dim, self.f_off, self.F_local)
 
 
-def run_sharded_selection(stages, shard: Optional[FeatureShard], S: int, exchange, after_stage0=None):
+def run_sharded_selection(stages, shard: Optional[FeatureShard], S: int, exchange, after_stage0=None, tie_radix=False):
     """Collective schedule of the sharded BatchTopK / PerLayerBatchTopK selection (include/clt_hip.h,
     clt_select_lists_sharded_f32).  `stages(lo, hi)` runs the local kernels of stages lo..hi; `exchange` maps
     "lb" -> int32 [S, 4] records (column 0 = lower-bound key), "hist" -> int32 [S*2048 + S], "ties" -> int32
@@ -99,6 +109,12 @@ def run_sharded_selection(stages, shard: Optional[FeatureShard], S: int, exchang
     for st in (1, 2, 3):
         stages(st, st)
         shard.all_reduce_sum(exchange["hist"])
+    if tie_radix:            # exact for any number of ties: radix select on the global flat index among the tied entries
+        for st in (4, 5, 6, 7):
+            stages(st, st)
+            shard.all_reduce_sum(exchange["hist"])
+        stages(8, 8)
+        return
     stages(4, 4)
     shard.all_gather_blocks(exchange["ties"])
     stages(5, 5)

@@ -131,6 +131,12 @@ size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n);
 int clt_mse_bf16_colsum_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std, int rows,
                             int n, float grad_scale, uint16_t* g16, float* colsum, int accumulate, double* loss_sum,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same pass over a layer-major slab (feature-sharded step, pipelined exchange: one launch per group of layers whose
+ * all-reduce has completed): r / g16 are [layers][layer_rows][n] (rows = layers * layer_rows, layer_rows % 64 == 0), the target
+ * row of (layer, token) is y + token * y_row_stride + layer * n (a [B][2][L][d] batch), mean / std / colsum are [layers][n]. */
+int clt_mse_bf16_colsum_layers_f32(const float* r, const float* y, long y_row_stride, const float* mean, const float* std, int rows,
+                                   int n, int layer_rows, float grad_scale, uint16_t* g16, float* colsum, int accumulate,
+                                   double* loss_sum, void* workspace, size_t workspace_bytes, void* stream);
 /* clt_mse_bf16_colsum_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference: same arithmetic and same results as the entry
  * point above, but the partial sums live in a fixed 4 MiB device array owned by the library (one per GPU, held until the
@@ -263,6 +269,11 @@ int clt_select_lists_f32(const float* x, const uint8_t* col_mask, int B, int L, 
  *   after 4: ALL-GATHER of the per-rank tie blocks (offset 3, info 4 words each; rank r's block is block r)
  *   5: emit + list build; used_fallback[0] != 0 afterwards means the candidate set was insufficient on some rank
  *      (nothing was emitted): the host re-runs all stages with exhaustive = 1 (every element is a candidate).
+ * exhaustive = 9 (1 | 8) is the form without tie lists, exact for ANY number of entries tied at the k-th value (the tie
+ * blocks hold 4096 per shard and segment): stages 0..3 as above, then
+ *   after 4, 5, 6, 7: SUM over ranks of the same uint32 array (256-bin histograms of a radix select on the GLOBAL flat
+ *      index among the tied entries: the lowest indices win);  8: emit + list build.  The host runs it when the
+ *      exhaustive = 1 attempt reports a tie-list overflow.
  * Replaces the DTensor plumbing of model/parallel.py, which cannot shard TopK modules at all (parallel.py:268-274). */
 size_t clt_select_lists_sharded_workspace_bytes(int B, int L, int F, int k, int mode, int world, int exhaustive);
 size_t clt_select_lists_exchange_info(int B, int L, int F, int k, int mode, int world, int exhaustive, int which);
@@ -320,10 +331,13 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
 /* out[b,l,:] = bias[l] + sum over entries (l',i,val) of token b with l' <= l (cross_layer) or l' == l of
  * val * Wptr[l][row,:], row = l'*F+i (cross_layer: W_l is [(l+1)F][d]) or i (per-layer: Wptr[l] = W + l*F*d).
  * Wptr: DEVICE array of L device pointers (to fp32 rows, or — w_bf16 != 0 — to the bf16 shadow copies that the
- * Adam row pass maintains: half the gathered bytes in bf16 mode). */
+ * Adam row pass maintains: half the gathered bytes in bf16 mode).  out[b,l,:] starts at out + b*out_tok_stride +
+ * l*out_layer_stride (elements; both 0 = the contiguous [B][L][d] layout): the feature-sharded step writes the partial
+ * reconstruction layer-major ([L][B][d]) so that every layer's slab is one contiguous all-reduce. */
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val,
                                const float* const* Wptr, const float* bias, float* out, int B, int L, int F, int d,
-                               int cross_layer, uint32_t cap, int w_bf16, void* stream);
+                               int cross_layer, uint32_t cap, int w_bf16, long out_tok_stride, long out_layer_stride,
+                               void* stream);
 /* One streaming pass over `rows` weight rows W[r][0:d] (row r <-> CSC column col0 + r):
  *   grad[r,:]  = sum_{p in column} coef[p] * src[tok[p], layer, :]   (+ the same over the optional 2nd list)
  *   dot_out[slot*dot_stride + p] = src[tok[p], layer, :] . W[r,:]    (pre-update weights; dot_out2: the same for

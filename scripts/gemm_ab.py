@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""A/B of NT-GEMM kernel variants in ONE process (cdna_hip_programming.md §5.4 rule 24): every variant is its own
+build of libclt_hip (ab/libclt_hip_v<N>.so, `make -C crosslayer_transcoder_amd/csrc variant V=<N>`), loaded side by
+side through ctypes; rounds are interleaved, random operands, HIP-event timed; prints median / min TFLOP/s.
+
+    python scripts/gemm_ab.py 0 1 2            # variants to compare (0 = the shipped library)
+"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, I, L = C.c_void_p, C.c_int, C.c_long
+
+
+def load(v):
+    path = os.path.join(ROOT, "crosslayer_transcoder_amd", "libclt_hip.so") if v == "0" else os.path.join(ROOT, "ab", f"libclt_hip_v{v}.so")
+    lib = C.CDLL(path)
+    lib.clt_gemm_bf16.restype = I
+    lib.clt_gemm_bf16.argtypes = [P, P, P, I, I, I, L, L, L, I, I, I, L, L, L, P, L, I, P]
+    return lib
+
+
+# (name, M, N, K, batch, lda, ldb, ldc, sA, sB, sC, flops-scale)
+def shapes():
+    B_, Lr, d, F = 4096, 12, 768, 32768
+    return [
+        ("8192^3", 8192, 8192, 8192, 1, 8192, 8192, 8192, 0, 0, 0),
+        ("4096^3", 4096, 4096, 4096, 1, 4096, 4096, 4096, 0, 0, 0),
+        ("enc fwd  M4096 K768 N32768 x12", B_, F, d, Lr, Lr * d, d, Lr * F, d, d * F, F),
+        ("wgrad    M32768 N768 K4096 x12", F, d, B_, Lr, B_, B_, d, F * B_, d * B_, F * d),
+        ("dec fwd  M4096 N768 K32768 x12", B_, d, F, Lr, Lr * F, F, Lr * d, F, d * F, d),
+    ]
+
+
+def main():
+    variants = sys.argv[1:] or ["0"]
+    libs = {v: load(v) for v in variants}
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    rounds = int(os.environ.get("ROUNDS", 7))
+    for (name, M, N, K, batch, lda, ldb, ldc, sA, sB, sC) in shapes():
+        a_elems = max((batch - 1) * sA + (M - 1) * lda + K, 1)
+        b_elems = max((batch - 1) * sB + (N - 1) * ldb + K, 1)
+        c_elems = max((batch - 1) * sC + (M - 1) * ldc + N, 1)
+        A = (torch.rand(a_elems, device=dev) * 2 - 1).bfloat16()
+        Bm = (torch.rand(b_elems, device=dev) * 2 - 1).bfloat16()
+        Cm = torch.empty(c_elems, dtype=torch.float32, device=dev)
+        ref = None
+        res = {v: [] for v in variants}
+        for r in range(rounds + 1):
+            for v in variants:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 3
+                e0.record()
+                for _ in range(reps):
+                    rc = libs[v].clt_gemm_bf16(A.data_ptr(), Bm.data_ptr(), Cm.data_ptr(), M, N, K, lda, ldb, ldc, 0, 1, batch, sA, sB, sC,
+                                               None, 0, 0, st)
+                    assert rc == 0, rc
+                e1.record()
+                torch.cuda.synchronize()
+                if r == 0:                     # warm-up round doubles as a cross-variant result check
+                    chk = Cm[: min(c_elems, 1 << 22)].clone()
+                    if ref is None:
+                        ref = chk
+                    else:
+                        assert torch.equal(chk, ref), f"variant {v} differs from variant {variants[0]} on {name}"
+                    continue
+                res[v].append(2.0 * M * N * K * batch * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        print(f"{name:34s} " + "  ".join(f"v{v}: med {statistics.median(res[v]):7.1f} max {max(res[v]):7.1f}" for v in variants), flush=True)
+        del A, Bm, Cm
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

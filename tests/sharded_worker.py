@@ -110,6 +110,20 @@ def gpu_selection_ties(rank, world):
                     ref = O.per_layer_batch_topk_fwd(xm, k)[0]
                     assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), \
                         f"layer k={k} ties={tie_heavy}"
+    # far more exact ties at the k-th value than a tie block holds (4096 per shard and segment): the exhaustive form with
+    # the index radix select must take over — and still pick the lowest global indices
+    B, L, F = 64, 3, 512
+    shard = FeatureShard(F, keep_single=KEEP_SINGLE)
+    x = torch.randint(0, 3, (B, L, F), generator=g).float() + 0.5        # three distinct values: ~32k ties per value
+    xl = shard.slice_features(x, 2).contiguous().cuda()
+    for k in (5, 100, 300):
+        S = ops.select_lists_sharded(xl, k, ops.SELECT_BATCH, shard, torch.zeros(1, device="cuda"), 0.1, None)
+        assert S.tie_radix, "expected the tie-radix form (tie lists overflow)"
+        ref = O.batch_topk_fwd(x, k)[0]
+        assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), f"tie radix batch k={k}"
+        S = ops.select_lists_sharded(xl, k, ops.SELECT_LAYER, shard, torch.zeros(L, device="cuda"), 0.1, None)
+        ref = O.per_layer_batch_topk_fwd(x, k)[0]
+        assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), f"tie radix layer k={k}"
 
 
 def gpu_list_capacity_overflow(rank, world):
@@ -218,7 +232,8 @@ def sim_selection(rank, world):
         u = torch.where(u == 0x80000000, torch.zeros_like(u), u)
         return torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u | 0x80000000)
 
-    for trial, (B, L, F, k, ties) in enumerate([(6, 3, 16, 2, False), (5, 2, 24, 3, True), (4, 1, 8, 8, False)]):
+    for trial, (B, L, F, k, ties, radix) in enumerate([(6, 3, 16, 2, False, False), (5, 2, 24, 3, True, False), (4, 1, 8, 8, False, False),
+                                                       (5, 2, 24, 3, True, True), (7, 3, 16, 5, True, True)]):
         g = torch.Generator().manual_seed(100 + trial)
         x = torch.randn(B, L, F, generator=g)
         if ties:
@@ -274,6 +289,33 @@ def sim_selection(rank, world):
                     find(s - 2)
                     sel = st["ck"][(st["ck"] & st["mask"]) == st["prefix"]]
                     ex["hist"][:NBIN] += torch.bincount((sel >> SHIFT[s - 1]) & ((1 << BITS[s - 1]) - 1), minlength=NBIN).to(torch.int32)
+                elif radix and s >= 4:
+                    # exhaustive tie resolution: radix select (4 x 8 bits, ascending) on the global index among the tied entries
+                    if s == 4:
+                        find(2)
+                        st["tx"] = {"prefix": 0, "mask": 0, "krem": st["krem"]}
+                    else:
+                        h = ex["hist"][:256].to(torch.int64)
+                        shift, cum = 24 - 8 * (s - 5), 0
+                        for b in range(256):
+                            if cum + int(h[b]) >= st["tx"]["krem"] or b == 255:
+                                break
+                            cum += int(h[b])
+                        st["tx"]["prefix"] |= b << shift
+                        st["tx"]["mask"] |= 255 << shift
+                        st["tx"]["krem"] -= cum
+                        ex["hist"][:NBIN] = 0
+                    tied = st["ci"][st["ck"] == st["prefix"]]
+                    if s < 8:
+                        if st["eq"] != st["krem"]:
+                            sel = tied[(tied & st["tx"]["mask"]) == st["tx"]["prefix"]]
+                            ex["hist"][:256] += torch.bincount((sel >> (24 - 8 * (s - 4))) & 255, minlength=256).to(torch.int32)
+                    else:
+                        T = st["prefix"]
+                        take = st["ck"] > T
+                        eq = st["ck"] == T
+                        take |= eq & ((st["ci"] <= st["tx"]["prefix"]) if st["eq"] != st["krem"] else torch.ones_like(eq))
+                        result["idx"] = st["ci"][take]
                 elif s == 4:
                     find(2)
                     T = st["prefix"]
@@ -294,7 +336,7 @@ def sim_selection(rank, world):
                         take |= eq
                     result["idx"] = st["ci"][take]
 
-        run_sharded_selection(stages, shard, 1, ex)
+        run_sharded_selection(stages, shard, 1, ex, tie_radix=radix)
         ref, ridx, _ = O.batch_topk_fwd(x, k)
         mine = set(int(i) for i in result["idx"])
         want = set(int(i) for i in ridx if shard.f_off <= int(i) % F < shard.f_off + Fl)
