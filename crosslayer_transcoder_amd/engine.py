@@ -431,6 +431,12 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     theta = None
     feat = S = pre = fused_ops = dpreT = None
     batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
+    probe = getattr(nl, "_kth_probe", None)
+    if probe is not None and probe.value():
+        # the last unfused selection ended in its exhaustive fallback, which leaves no k-th key behind: a fused attempt
+        # from it would be void (one wasted encoder GEMM) — skip it this step
+        nl._kth = None
+    nl._kth_probe = None
     if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
             and getattr(nl, "_kth", None) is not None and d % 8 == 0 and F % 4 == 0):
         mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
@@ -456,6 +462,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         S = _select_lists(nl, pre, shard=shard)
         if batch_mode:
             nl._kth = getattr(S, "kth", None)
+            if shard is None and nl._kth is not None and S.used_fallback is not None:
+                nl._kth_probe = ops.FlagProbe(S.used_fallback)        # (read at the next step, without blocking)
     elif fuse_jump:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
         fused_ops = ops.jumprelu_fwd_bf16(pre, theta)            # (feat bf16, feat^T bf16, fired)

@@ -7,6 +7,7 @@ checkpoints stay interchangeable (pinned by the reference's tests/test_save_to_p
 on load, both that prefix and this package's own are accepted and resolve to the classes here.
 """
 import importlib
+import re
 from pathlib import Path
 from typing import Any, Dict, Union
 
@@ -26,8 +27,16 @@ def resolve_class(class_path: str):
     return getattr(importlib.import_module(mod_name), cls_name)
 
 
+#: PyYAML (YAML 1.1) reads exponent-only numbers such as `1e-3` — the spelling of the reference's configs
+#: (config/debug-cpu.yaml: `learning_rate: 1e-3`, `pre_actv_loss: 1e-6`) — as strings; jsonargparse turns them into
+#: floats from the constructor's annotations.  Same effect here.
+_SCI_NUMBER = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+$")
+
+
 def build_from_config(node: Any):
     """Instantiate a {"class_path", "init_args"} tree (the LightningCLI / jsonargparse subclass schema)."""
+    if isinstance(node, str) and _SCI_NUMBER.match(node):
+        return float(node)
     if isinstance(node, dict) and "class_path" in node:
         cls = resolve_class(node["class_path"])
         kwargs = {k: build_from_config(v) for k, v in (node.get("init_args") or {}).items()}

@@ -917,6 +917,20 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     return s, T
 
 
+class FlagProbe:
+    """Host view of a device int32 flag that never blocks: the copy to pinned memory is queued on the current stream now;
+    value() returns the flag once that copy has completed, None before."""
+
+    def __init__(self, flag: torch.Tensor):
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.host.copy_(flag, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def value(self) -> Optional[int]:
+        return int(self.host) if self.ev.query() else None
+
+
 _FLAG_READERS = {}
 
 

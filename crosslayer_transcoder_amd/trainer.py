@@ -86,15 +86,19 @@ def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0"
     return losses, opt
 
 
-def run_config(cfg, device="cuda:0", max_steps: Optional[int] = None, fused: Optional[bool] = None, tensor_file=None):
+def run_config(cfg, device="cuda:0", max_steps: Optional[int] = None, fused: Optional[bool] = None, tensor_file=None,
+               init_state: Optional[dict] = None):
     """`python main.py fit --config X.yaml` without LightningCLI: seed, precision, model tree, data module, fit.
-    cfg: path or loaded dict.  tensor_file overrides data.init_args.tensor_file.  Returns (module, losses)."""
+    cfg: path or loaded dict.  tensor_file overrides data.init_args.tensor_file; init_state: a state dict loaded into
+    module.model before training (non-strict: e.g. the parameters of a checkpoint).  Returns (module, losses)."""
     if isinstance(cfg, str):
         cfg = load_config(cfg)
     if cfg.get("seed_everything") is not None:
         torch.manual_seed(int(cfg["seed_everything"]))
     apply_trainer_precision(cfg)
     module = build_module(cfg)
+    if init_state is not None:
+        module.model.load_state_dict(init_state, strict=False)
     dm = build_datamodule(cfg)
     if dm is None:
         raise ValueError("config has no data: section")

@@ -91,7 +91,7 @@ def test_jumprelu_configs_full_shape(cfg):
             p = pre[b, lo:l + 1]
             f = torch.where((p > theta[0, lo:l + 1]) & (p > 0), p, torch.zeros((), device=p.device)).bfloat16().double()
             W = (Ws[l] if a.decoder == "clt" else Ws[0][l:l + 1]).bfloat16().double()
-            ref = torch.einsum("sf,sfd->d", f, W) + mod.model.decoder.b[l].double()
+            ref = torch.einsum("sf,sfd->d", f, W.detach()) + mod.model.decoder.b[l].detach().double()
             assert torch.allclose(r[b, l].double(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max())), (cfg, b, l)
         del mod, out, pre, r
         torch.cuda.empty_cache()

@@ -480,3 +480,27 @@ def test_threshold_list_gate_chooses_the_regime():
         assert_close(out["loss"], out2["loss"], 1e-5, 1e-8, "loss: list regime vs dense regime")
         for k, g2 in out2["grads"].items():
             assert_close(out["grads"][k].reshape(g2.shape), g2, 1e-4, 2e-6 * float(g2.abs().max()) + 1e-12, f"grad {k}")
+
+
+def test_debug_yaml_config_end_to_end(tmp_path, golden):
+    """BASELINE.json configs[0] through the YAML itself: config/debug-cpu.yaml (the reference's class_path / init_args
+    trees) -> seed, precision "32", model tree, TensorDataModule on the reference's fixture tensor, 100 fused training
+    steps.  From the reference's initial parameters the loss curve must follow the curve the reference produced
+    (tests/golden/dbg_yaml_curve.pt); every batch is the whole 16-row tensor in a shuffled order, so the data module's
+    own permutations change nothing but the summation order."""
+    import os
+    from crosslayer_transcoder_amd import get_precision, trainer
+    cur = golden("dbg_yaml_curve")
+    acts = golden("dbg_jumprelu_clt")["batches"][0]
+    tfile = str(tmp_path / "debug_actvs.pt")
+    torch.save(acts, tfile)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fused in (True, False):
+        mod, losses = trainer.run_config(os.path.join(root, "config", "debug-cpu.yaml"), tensor_file=tfile,
+                                         init_state=cur["init_params"], fused=fused)
+        assert get_precision() == "32" and len(losses) == 100 and mod.global_step == 100
+        got = torch.stack([x.float().cpu() for x in losses])
+        assert_close(got[:5], cur["losses"][:5], 2e-5, 1e-7, "first steps")
+        assert_close(got, cur["losses"], 5e-4, 1e-7, f"100-step curve (fused={fused})")
+        for k, p in mod.model.named_parameters():
+            assert_close(p, cur["final_params"][k], 1e-3, 0.05, f"final {k}")
