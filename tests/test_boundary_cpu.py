@@ -108,3 +108,21 @@ def test_reference_yaml_configs_instantiate(name):
     if small:
         opt = conf["optimizer"] if isinstance(conf, dict) else conf
         assert opt.param_groups[0]["lr"] == cfg["model"]["init_args"]["learning_rate"]
+
+
+def test_own_debug_config_builds_module_and_datamodule():
+    """config/debug-cpu.yaml of this repository (BASELINE.json configs[0]): model tree, optimizer / scheduler and the
+    TensorDataModule of its data: section."""
+    from crosslayer_transcoder_amd import trainer
+    cfg = trainer.load_config(os.path.join(ROOT, "config", "debug-cpu.yaml"))
+    mod = trainer.build_module(cfg)
+    assert type(mod).__name__ == "JumpReLUCrossLayerTranscoderModule" and mod.fused_step and not mod.automatic_optimization
+    conf = mod.configure_optimizers()
+    assert conf["optimizer"].param_groups[0]["lr"] == 1e-3 and conf["lr_scheduler"]["name"] == "step_decay"
+    dm = trainer.build_datamodule(cfg)
+    assert dm.batch_size == 16 and dm.shuffle and dm.tensor_file.endswith("debug_actvs.pt")
+    with pytest.warns(UserWarning, match="16-mixed"):
+        trainer.apply_trainer_precision({"trainer": {"precision": "16-mixed"}})
+    from crosslayer_transcoder_amd import get_precision, set_precision
+    assert get_precision() == "bf16"
+    set_precision("32")
