@@ -107,7 +107,9 @@ def test_reference_yaml_configs_instantiate(name):
     conf = mod.configure_optimizers() if small else None
     if small:
         opt = conf["optimizer"] if isinstance(conf, dict) else conf
-        assert opt.param_groups[0]["lr"] == cfg["model"]["init_args"]["learning_rate"]
+        # (PyYAML reads the reference's `1e-3` spelling as a string; the loader turns it into the float jsonargparse would)
+        assert opt.param_groups[0]["lr"] == float(cfg["model"]["init_args"]["learning_rate"]) == 1e-3
+        assert isinstance(mod.pre_actv_loss, float) and mod.pre_actv_loss == 1e-6
 
 
 def test_own_debug_config_builds_module_and_datamodule():
