@@ -19,12 +19,14 @@ static inline bool diag_env(const char*) { return false; }
 #endif
 
 // fp32 -> bf16, round to nearest even (NaN stays NaN through the compiler's cvt on gfx950).
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even, by gfx950's packed conversion (v_cvt_pk_bf16_f32): lo in bits 0..15, hi in 16..31
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 clt_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float clt_f32x2 __attribute__((ext_vector_type(2)));
+    const clt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, clt_bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)pack_bf16x2(f, 0.0f); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // Order-preserving key of an fp32 value (ascending key == ascending value; -0 folded onto +0).
@@ -72,4 +74,4 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
                            const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st);
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr);
+                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false);

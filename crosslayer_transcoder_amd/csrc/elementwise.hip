@@ -100,6 +100,12 @@ __device__ __forceinline__ float rect_window(float x, float th, float bw) {
     return ((u + 0.5f > 0.0f) ? 1.0f : 0.0f) - ((u - 0.5f > 0.0f) ? 1.0f : 0.0f);
 }
 
+// (bf16 regime: the division by the bandwidth as a multiplication by its reciprocal)
+__device__ __forceinline__ float rect_window_rcp(float x, float th, float inv_bw) {
+    const float u = (x - th) * inv_bw;
+    return ((u + 0.5f > 0.0f) ? 1.0f : 0.0f) - ((u - 0.5f > 0.0f) ? 1.0f : 0.0f);
+}
+
 // grid: (ceil(n/256), chunks).  Each thread owns one column j and a contiguous chunk of rows.
 __global__ void jumprelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ theta, float bw,
                                     const float* __restrict__ g, float* __restrict__ dx, float* __restrict__ part,
@@ -373,34 +379,45 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
 // transposed [L*F][tokens] for the decoder weight gradient — and the same for d(loss)/d(pre-activations) of the
 // encoder weight gradient.  These kernels read the fp32 pre-activations ONCE per direction and write the bf16 operands
 // directly (no fp32 feature / dpre tensor, no separate cast, transpose, column-sum or any-positive passes).
-// Tile: 64 rows (tokens) x 256 columns; a thread owns 4 consecutive columns of rows w, w+4, ...; the transposed copy goes
-// through LDS (row pitch 129 dwords: conflict-free b32 stores, 32 distinct banks per transposed u16 read instruction).
-constexpr int FT_R = 64, FT_C = 256, FT_PITCH = 258;      // pitch in bf16 elements (= 129 dwords)
+// Tile: 64 rows (tokens) x 256 columns; a thread owns 4 consecutive columns of the row PAIRS w, w+4, ... (rows 2p, 2p+1).
+// The transposed copy goes through LDS as [32 pairs][256] dwords, a dword = (row 2p, row 2p+1) of one column — one packed
+// conversion produces it, and the transposed read-out takes 8 rows of a column with 4 b32 reads (pitch 258 dwords: the 8 row
+// groups x 8 columns of a wave-instruction fall on 64 distinct banks).
+constexpr int FT_R = 64, FT_C = 256, FT_PITCH = 258;      // pitch in dwords
 
-__device__ __forceinline__ void ft_store_row(uint16_t (*tile)[FT_PITCH], int r, int tx, const uint16_t h[4]) {
-    uint32_t* p = reinterpret_cast<uint32_t*>(&tile[r][4 * tx]);
-    p[0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-    p[1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+__device__ __forceinline__ void ft_store_pair(uint32_t (*tile)[FT_PITCH], int p, int tx, const float a[4], const float b[4]) {
+    uint2* q = reinterpret_cast<uint2*>(&tile[p][4 * tx]);
+    q[0] = make_uint2(pack_bf16x2(a[0], b[0]), pack_bf16x2(a[1], b[1]));
+    q[1] = make_uint2(pack_bf16x2(a[2], b[2]), pack_bf16x2(a[3], b[3]));
 }
 // transposed write-out of a [64][256] bf16 tile: column c gets 64 consecutive rows (128 B); 8 threads x 16 B per column
-__device__ __forceinline__ void ft_write_transposed(const uint16_t (*tile)[FT_PITCH], uint16_t* __restrict__ outT, long c0, int r0,
+__device__ __forceinline__ void ft_write_transposed(const uint32_t (*tile)[FT_PITCH], uint16_t* __restrict__ outT, long c0, int r0,
                                                     int rows, int n) {
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int idx = it * 256 + threadIdx.x, c = idx >> 3, rg = idx & 7;
-        uint32_t q[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            q[j] = (uint32_t)tile[rg * 8 + 2 * j][c] | ((uint32_t)tile[rg * 8 + 2 * j + 1][c] << 16);
+        const uint4 q = make_uint4(tile[rg * 4][c], tile[rg * 4 + 1][c], tile[rg * 4 + 2][c], tile[rg * 4 + 3][c]);
         if (c0 + c < n && r0 + rg * 8 < rows)
-            *reinterpret_cast<uint4*>(outT + (c0 + c) * (long)rows + r0 + rg * 8) = make_uint4(q[0], q[1], q[2], q[3]);
+            *reinterpret_cast<uint4*>(outT + (c0 + c) * (long)rows + r0 + rg * 8) = q;
     }
 }
 
+// four consecutive elements of an activation tensor held as fp32 (BF = false) or bf16 (BF = true: the dense bf16 regime's
+// GEMMs can leave pre-activations and feature gradients as bf16, clt_gemm_bf16_nt_out16)
+template <bool BF> __device__ __forceinline__ float4 act_load4(const void* __restrict__ base, long idx) {
+    if (BF) {
+        const ushort4 h = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(base) + idx);
+        return make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+    }
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+}
+
 // grid (ceil(n/256), ceil(rows/64)); rows % 8 == 0, n % 4 == 0
-__global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ theta, int rows,
+template <bool XB>
+__global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta, int rows,
                                                                 int n, uint16_t* __restrict__ feat, uint16_t* __restrict__ featT,
                                                                 uint8_t* __restrict__ fired) {
-    __shared__ uint16_t tile[FT_R][FT_PITCH];
+    __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
     const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long c0 = (long)blockIdx.x * FT_C;
     const int r0 = blockIdx.y * FT_R;
@@ -409,18 +426,30 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const float* __r
     float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (theta && cin) th = *reinterpret_cast<const float4*>(theta + col);
     bool any[4] = {false, false, false, false};
-    for (int i = 0; i < 16; ++i) {
-        const int r = w + 4 * i, row = r0 + r;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const bool in = cin && row < rows;
-        if (in) v = *reinterpret_cast<const float4*>(x + (long)row * n + col);
-        const float f[4] = {(v.x > th.x && v.x > 0.0f) ? v.x : v.x * 0.0f, (v.y > th.y && v.y > 0.0f) ? v.y : v.y * 0.0f,
-                            (v.z > th.z && v.z > 0.0f) ? v.z : v.z * 0.0f, (v.w > th.w && v.w > 0.0f) ? v.w : v.w * 0.0f};
-        uint16_t h[4];
+    for (int i0 = 0; i0 < 8; i0 += 2) {                    // two row pairs (four rows) loaded ahead of their arithmetic
+        float4 vv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { h[k] = f32_to_bf16(f[k]); any[k] |= f[k] > 0.0f; }
-        if (in) *reinterpret_cast<uint2*>(feat + (long)row * n + col) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-        ft_store_row(tile, r, tx, h);
+        for (int u = 0; u < 4; ++u) {
+            const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
+            vv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (cin && row < rows) vv[u] = act_load4<XB>(x, (long)row * n + col);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pr = w + 4 * (i0 + u), row = r0 + 2 * pr;
+            float f[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float4 v = vv[2 * u + e];
+                f[e][0] = (v.x > th.x && v.x > 0.0f) ? v.x : v.x * 0.0f; f[e][1] = (v.y > th.y && v.y > 0.0f) ? v.y : v.y * 0.0f;
+                f[e][2] = (v.z > th.z && v.z > 0.0f) ? v.z : v.z * 0.0f; f[e][3] = (v.w > th.w && v.w > 0.0f) ? v.w : v.w * 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) any[k] |= f[e][k] > 0.0f;
+                if (cin && row + e < rows)
+                    *reinterpret_cast<uint2*>(feat + (long)(row + e) * n + col) = make_uint2(pack_bf16x2(f[e][0], f[e][1]), pack_bf16x2(f[e][2], f[e][3]));
+            }
+            ft_store_pair(tile, pr, tx, f[0], f[1]);
+        }
     }
     if (cin) {                                         // fired[] is zeroed by the host wrapper; equal-value stores may race
 #pragma unroll
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const float* __r
 // its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
 __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
                                                           uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate) {
-    __shared__ uint16_t tile[FT_R][FT_PITCH];
+    __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
     const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r0 = blockIdx.x * FT_R;
     const long boff = (long)blockIdx.y * rows * n;
@@ -451,16 +480,20 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
         const long col = c0 + 4 * tx;
         const bool cin = col < n;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = w + 4 * i, row = r0 + r;
-            const bool in = cin && row < rows;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (in) v = *reinterpret_cast<const float4*>(W + (long)row * n + col);
-            acc[i] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            const uint16_t h[4] = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
-            if (in && op)
-                *reinterpret_cast<uint2*>(op + (long)row * n + col) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            ft_store_row(tile, r, tx, h);
+        for (int i = 0; i < 8; ++i) {                       // row pair w + 4 i: rows 2 (w + 4 i), + 1
+            const int pr = w + 4 * i, row = r0 + 2 * pr;
+            float f[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool in = cin && row + e < rows;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in) v = *reinterpret_cast<const float4*>(W + (long)(row + e) * n + col);
+                acc[2 * i + e] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                f[e][0] = v.x; f[e][1] = v.y; f[e][2] = v.z; f[e][3] = v.w;
+                if (in && op)
+                    *reinterpret_cast<uint2*>(op + (long)(row + e) * n + col) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            }
+            ft_store_pair(tile, pr, tx, f[0], f[1]);
         }
         if (opT) {
             __syncthreads();
@@ -472,7 +505,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float s = wave_sum(acc[i]);
-            const int row = r0 + w + 4 * i;
+            const int row = r0 + 2 * (w + 4 * (i >> 1)) + (i & 1);
             if (tx == 0 && row < rows) { float* q = sq + (long)blockIdx.y * rows + row; *q = accumulate ? *q + s : s; }
         }
     }
@@ -480,64 +513,94 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 
 // grid (ceil(n/256), ceil(rows/256)): a block walks 4 row tiles of its 256 columns, keeping the column partial sums in
 // registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
-__global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const float* __restrict__ x, const float* __restrict__ theta,
-                                                                 const float* __restrict__ sq, const float* __restrict__ dfm, float bw,
-                                                                 float lamB, float c, int use_tanh, float coefBL,
+template <bool XB, bool GB, bool TANH>
+__global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
+                                                                 const float* __restrict__ sq, const void* __restrict__ dfm, float bw,
+                                                                 float lamB, float c, float coefBL,
                                                                  uint16_t* __restrict__ dpreT, float* __restrict__ part,
                                                                  double* __restrict__ part_s, int rows, int n) {
-    __shared__ uint16_t tile[FT_R][FT_PITCH];
-    __shared__ float red[3][4][FT_C];
+    // (the kernel is bound by instruction issue, not by HBM: the element arithmetic is branch-free — out-of-range elements
+    // are loaded as zeros and masked where a zero input would still contribute —, per-column factors are hoisted, tanh runs
+    // on the hardware exp2 / rcp, and the loss sums of a lane's 64 elements of a row tile are taken in fp32 before they join
+    // the fp64 totals)
+    __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
     __shared__ double sh[4];
+    float (*red)[4][FT_C] = reinterpret_cast<float (*)[4][FT_C]>(&tile[0][0]);      // [3][4][256] floats: reuses the tile after the loop
+    static_assert(sizeof(float) * 3 * 4 * FT_C <= sizeof(uint32_t) * (FT_R / 2) * FT_PITCH, "red fits the tile");
     const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long c0 = (long)blockIdx.x * FT_C;
     const long col = c0 + 4 * tx;
     const bool cin = col < n;
-    float th[4] = {0, 0, 0, 0}, nrm[4] = {0, 0, 0, 0}, thc[4];
+    float th[4] = {0, 0, 0, 0}, nrm[4] = {0, 0, 0, 0};
     if (cin) {
         const float4 t4 = *reinterpret_cast<const float4*>(theta + col), s4 = *reinterpret_cast<const float4*>(sq + col);
         th[0] = t4.x; th[1] = t4.y; th[2] = t4.z; th[3] = t4.w;
         nrm[0] = sqrtf(s4.x); nrm[1] = sqrtf(s4.y); nrm[2] = sqrtf(s4.z); nrm[3] = sqrtf(s4.w);
     }
+    float thc[4], nc[4], nc2[4], lcn[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) thc[k] = -(th[k] / bw);
+    for (int k = 0; k < 4; ++k) {
+        thc[k] = -(th[k] / bw);
+        nc[k] = nrm[k] * c;                                  // weighted feature = f * nc
+        nc2[k] = nc[k] * 2.885390081777927f;                 // 2 log2(e): exp(2 wv) = exp2(f * nc2)
+        lcn[k] = lamB * c * nrm[k];                          // d(sparsity)/d(feature) = lcn * tanh'
+    }
+    const float hb = 0.5f * bw, ncoef = -coefBL;
     float a_th[4] = {0, 0, 0, 0}, a_dn[4] = {0, 0, 0, 0}, a_db[4] = {0, 0, 0, 0};
     double s_t = 0.0, s_p = 0.0, s_w = 0.0;
     for (int rt = 0; rt < 4; ++rt) {
         const int r0 = (blockIdx.y * 4 + rt) * FT_R;
         if (r0 >= rows) break;
-        for (int i = 0; i < 16; ++i) {
-            const int r = w + 4 * i, row = r0 + r;
-            const bool in = cin && row < rows;
-            float4 v4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g4 = v4;
-            if (in) {
-                v4 = *reinterpret_cast<const float4*>(x + (long)row * n + col);
-                g4 = *reinterpret_cast<const float4*>(dfm + (long)row * n + col);
-            }
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
-            uint16_t h[4];
+        float f_t = 0.0f, f_p = 0.0f, f_w = 0.0f;
+        for (int i0 = 0; i0 < 8; i0 += 2) {                  // two row pairs (four rows) loaded ahead of their arithmetic
+            float4 v4[4], g4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float f = (v[k] > th[k] && v[k] > 0.0f) ? v[k] : 0.0f;
-                const float wv = f * nrm[k] * c;
-                const float t = use_tanh ? tanhf(wv) : wv;
-                const float dt = use_tanh ? (1.0f - t * t) : 1.0f;
-                float dp = 0.0f;
-                if (in) {
-                    s_t += (double)t; s_w += (double)wv; s_p += (double)(v[k] < 0.0f ? -v[k] : 0.0f);
-                    const float df = gg[k] + lamB * dt * c * nrm[k];
-                    dp = (v[k] < 0.0f ? 0.0f : df) - (v[k] < 0.0f ? coefBL : 0.0f);
-                    a_th[k] += thc[k] * rect_window(v[k], th[k], bw) * df;
-                    a_dn[k] += lamB * dt * c * f;
-                    a_db[k] += dp;
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
+                v4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); g4[u] = v4[u];
+                if (cin && row < rows) {
+                    v4[u] = act_load4<XB>(x, (long)row * n + col);
+                    g4[u] = act_load4<GB>(dfm, (long)row * n + col);
                 }
-                h[k] = f32_to_bf16(dp);
             }
-            ft_store_row(tile, r, tx, h);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pr = w + 4 * (i0 + u);
+                float dpv[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float inm = (cin && r0 + 2 * pr + e < rows) ? 1.0f : 0.0f;
+                    const float v[4] = {v4[2 * u + e].x, v4[2 * u + e].y, v4[2 * u + e].z, v4[2 * u + e].w};
+                    const float gg[4] = {g4[2 * u + e].x, g4[2 * u + e].y, g4[2 * u + e].z, g4[2 * u + e].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float f = (v[k] > th[k] && v[k] > 0.0f) ? v[k] : 0.0f;
+                        const float wv = f * nc[k];
+                        float t = wv, dt = 1.0f;
+                        if (TANH) {                          // tanh(wv), wv >= 0, = 1 - 2 / (exp(2 wv) + 1); about 1e-6 absolute
+                            t = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(f * nc2[k]) + 1.0f), 1.0f);
+                            dt = fmaf(-t, t, 1.0f);
+                        }
+                        f_t += t; f_w += wv; f_p += fmaxf(-v[k], 0.0f);
+                        const float df = fmaf(dt, lcn[k], gg[k]) * inm;
+                        const float dp = v[k] < 0.0f ? ncoef : df;
+                        const float d = v[k] - th[k];        // rectangle window of the threshold's STE: -bw/2 < d <= bw/2
+                        a_th[k] = fmaf((d > -hb && d <= hb) ? thc[k] : 0.0f, df, a_th[k]);
+                        a_dn[k] = fmaf(dt, f, a_dn[k]);      // (times lamB * c after the loop)
+                        a_db[k] += dp;
+                        dpv[e][k] = dp;
+                    }
+                }
+                ft_store_pair(tile, pr, tx, dpv[0], dpv[1]);
+            }
         }
+        s_t += (double)f_t; s_w += (double)f_w; s_p += (double)f_p;
         __syncthreads();
         ft_write_transposed(tile, dpreT, c0, r0, rows, n);
         __syncthreads();
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a_dn[k] *= lamB * c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { red[0][w][4 * tx + k] = a_th[k]; red[1][w][4 * tx + k] = a_dn[k]; red[2][w][4 * tx + k] = a_db[k]; }
     __syncthreads();
@@ -834,30 +897,36 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
-int clt_jumprelu_fwd_bf16(const float* x, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT, uint8_t* fired,
-                          void* st) {
+int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT,
+                          uint8_t* fired, void* st) {
     if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
     if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta))) return CLT_ERR_ALIGN;
     if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel, dim3((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R), dim3(256), 0, as_stream(st),
-                       x, theta, rows, n, feat, featT, fired);
+    const dim3 grid((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R);
+    if (x_bf16) hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel<true>, grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired);
+    else hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel<false>, grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n) {
     const size_t gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C;
     return align_up(3 * gy * (size_t)n * sizeof(float), 16) + gx * gy * 3 * sizeof(double);
 }
-int clt_jumprelu_loss_bwd_bf16(const float* x, const float* theta, const float* sq, const float* dfm, float bw, float lamB, float c,
-                               int use_tanh, float coefBL, uint16_t* dpreT, float* dbias, float* dtheta, float* dnorm,
-                               double* sums, int rows, int n, void* ws, size_t wsb, void* st) {
+int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* sq, const void* dfm, int dfm_bf16, float bw,
+                               float lamB, float c, int use_tanh, float coefBL, uint16_t* dpreT, float* dbias, float* dtheta,
+                               float* dnorm, double* sums, int rows, int n, void* ws, size_t wsb, void* st) {
     if (rows <= 0 || n <= 0 || !x || !theta || !sq || !dfm || !dpreT || !dbias || !dtheta || !dnorm || !sums) return CLT_ERR_SHAPE;
     if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(theta) || !aligned16(sq) || !aligned16(dfm) || !aligned16(dpreT)) return CLT_ERR_ALIGN;
     if (!ws || wsb < clt_jumprelu_loss_bf16_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
     const int gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C, gc = (n + TPB - 1) / TPB;
     float* part = (float*)ws;
     double* ps = (double*)((char*)ws + align_up((size_t)3 * gy * n * sizeof(float), 16));
-    hipLaunchKernelGGL(jumprelu_loss_bf16_kernel, dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, dfm, bw, lamB, c, use_tanh,
-                       coefBL, dpreT, part, ps, rows, n);
+#define JL2(XB_, GB_, TH_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, \
+                                             dfm, bw, lamB, c, coefBL, dpreT, part, ps, rows, n)
+#define JL(XB_, GB_) do { if (use_tanh) JL2(XB_, GB_, true); else JL2(XB_, GB_, false); } while (0)
+    if (x_bf16) { if (dfm_bf16) JL(true, true); else JL(true, false); }
+    else { if (dfm_bf16) JL(false, true); else JL(false, false); }
+#undef JL2
+#undef JL
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * gy, 3, sums);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)part, gy, n, dtheta, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)gy * n), gy, n, dnorm, 0);

@@ -17,6 +17,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (kernel experiments are built as variants of this file — `make variant V=n` defines GEMM_VARIANT — and compared in one
+// process by scripts/gemm_ab.py; tried and rejected in round 2, all slower or equal on the shapes of the step: DMA pieces
+// spread over the MFMA groups instead of issued together, s_setprio around the MFMA groups, the bias as the initial
+// accumulator, an integer maximum-and-compare scan in the select epilogue: profiles/r02_gemm_ab.md)
 #ifndef GEMM_VARIANT
 #define GEMM_VARIANT 0
 #endif
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             vA[i] = (int)(((long)ra * lda + chunk * 8) * 2);
         }
         brow0 = (long)t.b0 * ldb;
-        rA = rsrc(A0 + ((EPI == 0 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
-        rB = rsrc(((EPI == 0 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
+        rA = rsrc(A0 + ((EPI != 1 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
+        rB = rsrc(((EPI != 1 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
     };
     typedef __attribute__((address_space(3))) void lds_void;
     auto stage = [&](int buf, int kt) {
@@ -132,28 +136,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         int sob = kt * (TK * 2);
         const int oob = kt == nk - 1 ? tail_oob : 0;
         __amdgpu_buffer_rsrc_t rb = rB;
-        if (EPI == 0 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
+        if (EPI != 1 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i] | oob, kt * (TK * 2), 0, 0);
-    };
-
-    // one DMA piece of a k-tile: q = 0..3 B pieces, 4..7 A pieces (so that the issue can be spread between MFMA groups)
-    auto stage_piece = [&](int buf, int kt, int q) {
-        unsigned char* base = nt_smem + buf * STAGE_BYTES;
-        const int oob = kt == nk - 1 ? tail_oob : 0;
-        const int i = q & 3;
-        if (q < 4) {
-            int sob = kt * (TK * 2);
-            __amdgpu_buffer_rsrc_t rb = rB;
-            if (EPI == 0 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 8 + w) * 1024), 16, vA[i] | oob, kt * (TK * 2), 0, 0);
-        }
     };
 
     // The tile's bias slice rides along as a ninth DMA piece of wave 0 (columns past N read as zero through the
@@ -192,7 +181,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         // first k-tile (staged before the previous tile's epilogue).  Vector-memory operations retire in issue order, so
         // after an interior tile's store epilogue (exactly 32 stores per lane, no loads) the prefetch is complete once all
         // but the 32 youngest operations are: the stores keep draining under the main loop
-        if (stores_after_prefetch) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        if (stores_after_prefetch) { if (EPI == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (bare s_barrier: __syncthreads() carries a release fence, i.e. a compiler-inserted vmcnt(0) that would wait for the
         // stores just issued; what the barriers of this kernel order is LDS traffic, waited for explicitly)
@@ -229,28 +218,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         if (r == 16) {
                             if (diag & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (ablation: no wait for the DMA — wrong results)
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if GEMM_VARIANT == 0
                             if (kt + 2 < nk) stage(kt & 1, kt + 2);
-#endif
 #pragma unroll
                             for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nbase, 0, n);
                         }
                         fb[r & 7] = ldB(nbase, 0, r & 7);
-#if GEMM_VARIANT == 1 || GEMM_VARIANT == 2
-                        // the restage of the buffer just freed, two DMA pieces per MFMA group (groups 12..15)
-                        if (kt + 2 < nk) { stage_piece(kt & 1, kt + 2, (r - 16) * 2); stage_piece(kt & 1, kt + 2, (r - 16) * 2 + 1); }
-#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#if GEMM_VARIANT == 2
-                    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[ks][n], acc[m][n], 0, 0, 0);
-#if GEMM_VARIANT == 2
-                    __builtin_amdgcn_s_setprio(0);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -334,6 +311,40 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                 const uint32_t pos = gbase + i;
                 if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
             }
+        } else if (EPI == 2) {
+            // ---- bf16 store epilogue: C leaves as bf16 (half the bytes AND half the store instructions of the fp32 form:
+            // the K = 768 contractions of the step are bound by pushing the tile out of the CU).  Same LDS transposition;
+            // a lane then takes 8 consecutive columns of one row (two b128 reads), adds the bias, rounds to nearest even
+            // and stores 16 bytes: 256-byte row segments, 4 rows per wave-instruction, exactly 16 stores per lane and tile.
+            uint16_t* C = reinterpret_cast<uint16_t*>(C0) + (long)batch * sC;
+            unsigned char* ebuf = nt_smem + EPI_BASE_STORE + w * (16 * EROW);
+            const int er = lane >> 4, ec = (lane & 15) * 8;
+            const int col = b0 + wm * 128 + ec;
+            f32x4 b0v = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, b1v = b0v;
+            if (bias) { b0v = *reinterpret_cast<const f32x4*>(bias + wm * 128 + ec); b1v = *reinterpret_cast<const f32x4*>(bias + wm * 128 + ec + 4); }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    *reinterpret_cast<f32x4*>(ebuf + fr * EROW + (m * 16 + fq * 4) * 4) = acc[m][n];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int lr = it * 4 + er;
+                    const int row = a0 + wn * 64 + n * 16 + lr;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4) + b0v;
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + lr * EROW + ec * 4 + 16) + b1v;
+                    if (row < M && col < N) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(1))) u32x4 gvec;
+                        u32x4 o;
+                        o[0] = pack_bf16x2(v0[0], v0[1]); o[1] = pack_bf16x2(v0[2], v0[3]);
+                        o[2] = pack_bf16x2(v1[0], v1[1]); o[3] = pack_bf16x2(v1[2], v1[3]);
+                        *(gvec*)(C + (long)row * ldc + col) = o;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         } else {
             // ---- store epilogue -------------------------------------------------------------------------------
             // A lane holds C[a-row fr][4 consecutive columns] of each 16x16 tile, i.e. 64-byte runs per row.  Each wave
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             }
         }
         if (!more) break;
-        stores_after_prefetch = EPI == 0 && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
+        stores_after_prefetch = EPI != 1 && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
         vb = nvb;
     }
 }
@@ -406,8 +417,10 @@ int persistent_grid(long nblk) {
 // to the generic kernel), or a negative error.
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups) {
+                              hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
+    // bf16 result (C is then a bf16 array; ldc / sC in bf16 elements): 8-column alignment, no accumulate, no groups
+    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
     const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
@@ -417,6 +430,15 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     if (nblk > 0x7fffffffL) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (out16) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel<2>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
+                           lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(), SelEpi{}, Bseg, kts,
+                           (const GemmGroup*)nullptr);
+        CLT_LAUNCH_CHECK();
+        return CLT_OK;
+    }
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
                        lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
                        gemm_diag(), SelEpi{}, Bseg, kts, grp);
@@ -432,6 +454,23 @@ extern "C" int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* B
     if (kseg % TK) return 1;
     return clt_internal_gemm_nt_bf16(A, nullptr, C, M, N, nseg * kseg, lda, ldb, ldc, 1, 0, 0, 0, bias, 0, accumulate, as_stream(stream),
                                      Bseg, kseg / TK);
+}
+
+// NT GEMMs whose result leaves as bf16 (C: bf16 [M][N], row stride ldc, batch stride sC, in bf16 elements): the dense bf16
+// regime's pre-activations and feature gradients are consumed once, elementwise, by kernels that round to bf16 anyway, and at
+// K = 768 the fp32 store is what bounds the kernel.  Fast kernel only: 1 when the shape does not qualify (N % 8, ldc % 8, ...).
+extern "C" int clt_gemm_bf16_nt_out16(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K, long lda, long ldb, long ldc,
+                                      int batch, long sA, long sB, long sC, const float* bias, long sBias, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !A || !B || !C) return CLT_ERR_SHAPE;
+    return clt_internal_gemm_nt_bf16(A, B, reinterpret_cast<float*>(C), M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias, sBias, 0,
+                                     as_stream(stream), nullptr, 0, nullptr, true);
+}
+extern "C" int clt_gemm_bf16_nt_kseg_out16(const uint16_t* A, const uint16_t* const* Bseg, uint16_t* C, int M, int N, int nseg, int kseg,
+                                           long lda, long ldb, long ldc, void* stream) {
+    if (M <= 0 || N <= 0 || nseg <= 0 || kseg <= 0 || !A || !Bseg || !C) return CLT_ERR_SHAPE;
+    if (kseg % TK) return 1;
+    return clt_internal_gemm_nt_bf16(A, nullptr, reinterpret_cast<float*>(C), M, N, nseg * kseg, lda, ldb, ldc, 1, 0, 0, 0, nullptr, 0, 0,
+                                     as_stream(stream), Bseg, kseg / TK, nullptr, true);
 }
 
 // Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -96,6 +98,8 @@ COMPACT_AUX = True
 COMPACT_AUX_MAX_SHARE = 0.5
 #: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
+#: dense bf16 JumpReLU regime: pre-activations / feature gradient stored as bf16 (CLT_DENSE_BF16_ACT=0: fp32, for A/B runs)
+DENSE_BF16_ACTIVATIONS = os.environ.get("CLT_DENSE_BF16_ACT", "1") != "0"
 FUSE_DENSE_JUMPRELU = True
 #: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
 FUSE_WEIGHT_PREP = True
@@ -210,10 +214,17 @@ class _Decoder:
             r = ops.clt_decoder_fwd(feat, self.Wop, self._bias()) if self.clt else ops.plt_decoder_fwd(feat, self.Wop[0], self._bias())
         return self._reduce(r)
 
-    def dgrad(self, g, go=None):
+    def dgrad(self, g, go=None, out_bf16=False):
+        """Feature gradient [B, L, F]; out_bf16: as bf16 when the bf16 kernels take the shape (else fp32 as always)."""
         go = _op(g) if go is None else go
         if self.clt and self.bf16:          # one K-segmented GEMM per source layer: the result is written once
-            df = ops.clt_decoder_dgrad_kseg(go, self.Wop)
+            df = ops.clt_decoder_dgrad_kseg(go, self.Wop, out_bf16)
+            if df is None and out_bf16:
+                df = ops.clt_decoder_dgrad_kseg(go, self.Wop)
+            if df is not None:
+                return df
+        if out_bf16 and self.bf16 and not self.clt:
+            df = ops.plt_decoder_dgrad_out16(go, self.Wop[0])
             if df is not None:
                 return df
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
@@ -447,10 +458,17 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             nl._kth = kth
         else:
             STATS["select_fallbacks"] += 1
-    if S is None:
-        pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
+    # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their
+    # GEMMs as bf16 — the K = d_acts GEMMs are bound by their epilogue stores, and the consumers read half the bytes
+    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None
+                 and not (sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0)))
+    if S is None:
+        pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), enc.b) if act16 else None
+        if pre is None:
+            act16 = False
+            pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     if S is None and sparse and thr_family:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
         S = _threshold_lists(mod, pre, theta, force_lists)
@@ -558,14 +576,17 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         out.lazy["recons_norm"] = lambda: r_lm.permute(1, 0, 2).contiguous()
     else:
         out["recons_norm"] = r
-    if pre is not None:
+    if pre is not None and not act16:
         out["pre_actvs"] = pre
+    elif pre is not None:
+        out.lazy["pre_actvs"] = lambda: pre.float()
     else:
         out.lazy["pre_actvs"] = lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     if feat is not None:
         out["features"] = feat
     elif fused_ops is not None:
-        out.lazy["features"] = (lambda: ops.jumprelu_fwd(pre, theta)) if theta is not None else (lambda: ops.relu_fwd(pre))
+        pre32 = (lambda: pre.float()) if act16 else (lambda: pre)
+        out.lazy["features"] = (lambda: ops.jumprelu_fwd(pre32(), theta)) if theta is not None else (lambda: ops.relu_fwd(pre32()))
 
     if lists_only:
         S2 = g_aux = cx = None
@@ -656,8 +677,9 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         bw = nl._bandwidth if theta is not None else 1.0
         sq = D.sqnorms()
         g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
-        dfeat = D.dgrad(g, go=g16)
-        if fused_ops is not None or (S is not None and fuse_jump):
+        loss16 = fused_ops is not None or (S is not None and fuse_jump)
+        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
+        if loss16:
             sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                                   mod.pre_actv_loss / (Bn * L))
         else:

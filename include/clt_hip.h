@@ -183,13 +183,15 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
  *                           fired[j] = any_r feat > 0 (K12).  theta may be NULL (ReLU).  No fp32 feature tensor.
  *   clt_jumprelu_loss_bwd_bf16: the math of clt_jumprelu_loss_bwd_f32, but d(loss)/d(pre) leaves only as the transposed
  *                           bf16 GEMM operand dpreT[j][r] plus its fp32 column sums dbias[j] (encoder bias gradient). */
-int clt_jumprelu_fwd_bf16(const float* x, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT, uint8_t* fired,
-                          void* stream);
+/* x (and dfeat_main) may be held as bf16 (x_bf16 / dfeat_bf16 != 0): what clt_gemm_bf16_nt_out16 leaves — under the
+ * reference's bf16 autocast the encoder's pre-activations are bf16 tensors as well (bmm output dtype). */
+int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT,
+                          uint8_t* fired, void* stream);
 size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n);
-int clt_jumprelu_loss_bwd_bf16(const float* x, const float* theta, const float* sq, const float* dfeat_main, float bandwidth,
-                               float lam_over_B, float c, int use_tanh, float coef_over_BL, uint16_t* dpreT, float* dbias,
-                               float* dtheta, float* dnorm, double* sums, int rows, int n, void* workspace, size_t ws_bytes,
-                               void* stream);
+int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* sq, const void* dfeat_main,
+                               int dfeat_bf16, float bandwidth, float lam_over_B, float c, int use_tanh, float coef_over_BL,
+                               uint16_t* dpreT, float* dbias, float* dtheta, float* dnorm, double* sums, int rows, int n,
+                               void* workspace, size_t ws_bytes, void* stream);
 /* dW[row][:] += (dnorm[row]/sqrt(sq[row])) * W[row][:]   (gradient through dec_norms). */
 int clt_rowscale_add_f32(const float* W, const float* dnorm, const float* sq, float* dW, int rows, int d,
                          void* stream);
@@ -290,6 +292,14 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
  * d_acts) in one pass and the output is written once.  Returns 1 when the shape does not qualify (kseg % 64, alignment). */
 int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* Bseg, float* C, int M, int N, int nseg, int kseg, long lda,
                           long ldb, long ldc, const float* bias, int accumulate, void* stream);
+/* NT GEMMs whose result leaves as bf16 (C: bf16 [M][N]; ldc, sC in bf16 elements; N % 8 == 0, ldc % 8 == 0): for the dense
+ * bf16 regime's pre-activations (clt.py:157-165 under bf16 autocast: a bf16 tensor in the reference too) and feature
+ * gradients, which are consumed once, elementwise.  Halves the bytes and the store instructions of the K = 768
+ * contractions' epilogue, which bounds them.  Fast kernel only: returns 1 when the shape does not qualify. */
+int clt_gemm_bf16_nt_out16(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K, long lda, long ldb, long ldc,
+                           int batch, long sA, long sB, long sC, const float* bias, long sBias, void* stream);
+int clt_gemm_bf16_nt_kseg_out16(const uint16_t* A, const uint16_t* const* Bseg, uint16_t* C, int M, int N, int nseg, int kseg,
+                                long lda, long ldb, long ldc, void* stream);
 /* Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
  * groups: DEVICE array of records {int64 aoff (elements into A); const uint16_t* B; float* C}.  Used for the dense
  * cross-layer decoder forward (clt.py:334-343): all (target layer, source layer) pairs — 78 at L = 12 — fill the chip

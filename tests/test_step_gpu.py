@@ -192,13 +192,16 @@ def test_pretrained_roundtrip_and_folding(tmp_path, golden):
     assert_close(recons_folded, recons, 1e-4, 1e-4 * float(recons.abs().max()), "folded recons")
 
 
-@pytest.mark.parametrize("dec_kind,nl_kind,loss_kind", [("clt", "jumprelu", "jumprelu"), ("plt", "jumprelu", "jumprelu"),
-                                                        ("clt", "relu", "base"), ("clt", "batchtopk", "base")])
-def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
+@pytest.mark.parametrize("dec_kind,nl_kind,loss_kind,act16", [("clt", "jumprelu", "jumprelu", False), ("plt", "jumprelu", "jumprelu", False),
+                                                              ("clt", "jumprelu", "jumprelu", True), ("plt", "jumprelu", "jumprelu", True),
+                                                              ("clt", "relu", "base", False), ("clt", "batchtopk", "base", False)])
+def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind, act16, monkeypatch):
     """Shapes large enough for the glds NT GEMM kernel (K % 64 == 0, M*N >= 256^2) in every dense contraction
     (decoder forward with transposed weights + slab sum, dgrad, token-contracted weight gradients): loss and
-    gradients vs the oracle run with the same bf16 operand rounding (rtol 2e-2, relative l2 for gradients)."""
-    from crosslayer_transcoder_amd import precision
+    gradients vs the oracle run with the same bf16 operand rounding (rtol 2e-2, relative l2 for gradients).
+    act16: the pre-activations and the feature gradient leave their GEMMs as bf16 (engine.DENSE_BF16_ACTIVATIONS)."""
+    from crosslayer_transcoder_amd import engine, precision
+    monkeypatch.setattr(engine, "DENSE_BF16_ACTIVATIONS", act16)
     from oracle import clt_oracle as O
     from tests.build_cases import build_module
     B, L, d, F = 512, 3, 128, 512
@@ -238,10 +241,14 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
         gg = out["grads"][k].reshape(gref.shape).cpu()
         rel = (gg - gref).norm() / (gref.norm() + 1e-12)
         assert rel < 2e-2, f"{dec_kind}/{nl_kind} bf16 grad {k}: rel l2 err {rel:.3g}"
-    if loss_kind == "jumprelu":
-        # the fused tile passes (bf16 operands written directly) against the separate fp32 passes + casts: the GEMM
-        # operands are bit-identical, only the column-sum / loss-sum reduction trees differ
-        from crosslayer_transcoder_amd import engine
+    if loss_kind == "jumprelu" and act16:
+        assert "pre_actvs" not in dict.keys(out) and out["pre_actvs"].dtype == torch.float32      # (lazy fp32 view of the bf16 tensor)
+        pre_ref = ref["pre"]
+        assert_close(out["pre_actvs"], pre_ref, 1e-2, 1e-2 * float(pre_ref.abs().max()), "bf16 pre-activations")
+    elif loss_kind == "jumprelu":
+        # the fused tile passes (bf16 operands written directly) against the separate fp32 passes + casts: the forward GEMM
+        # operands are bit-identical; the backward pass takes tanh from the hardware exp2 / rcp (about 1e-6 absolute), which can
+        # move a d(pre) entry across a bf16 rounding boundary, and its column-sum / loss-sum reduction trees differ
         assert "features" not in dict.keys(out), "the fused dense path should not materialise fp32 features"
         mod2 = build_module(case)
         mod2.global_step = 5
@@ -256,9 +263,10 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind):
         assert torch.equal(out["features"], out2["features"])
         assert torch.equal(out["recons_norm"], out2["recons_norm"])
         assert torch.equal(out["dead"], out2["dead"])
-        assert_close(out["loss"], out2["loss"], 1e-6, 0, "fused vs unfused loss")
+        assert_close(out["loss"], out2["loss"], 2e-6, 0, "fused vs unfused loss")
         for k, g2 in out2["grads"].items():
-            assert_close(out["grads"][k], g2, 1e-5, 1e-6 * float(g2.abs().max()), f"fused vs unfused grad {k}")
+            rel = float((out["grads"][k] - g2).norm() / (g2.norm() + 1e-12))
+            assert rel < 1e-3, f"fused vs unfused grad {k}: rel l2 err {rel:.3g}"
 
 
 @pytest.mark.parametrize("nl_kind", ["batchtopk", "perlayerbatchtopk"])
