@@ -10,6 +10,7 @@ import torch.nn as nn
 import yaml
 from safetensors.torch import save_file
 
+from .. import custom_ops  # noqa: F401  (registers torch.ops.clt_hip.*)
 from ..precision import get_precision
 from .serializable_module import SerializableModule
 from .standardize import Standardizer
@@ -26,26 +27,6 @@ def _operand(t: torch.Tensor) -> torch.Tensor:
     from .. import ops
     t = t.contiguous()
     return ops.cast_bf16(t) if get_precision() == "bf16" else t
-
-
-class _EncoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, xs, W, b):
-        from .. import ops
-        xo, Wo = _operand(xs), _operand(_feature_major(W))
-        ctx.save_for_backward(xo, Wo)
-        ctx.has_bias = b is not None
-        return ops.encoder_fwd(xo, Wo, b)
-
-    @staticmethod
-    def backward(ctx, dpre):
-        from .. import ops
-        xo, Wo = ctx.saved_tensors
-        do = _operand(dpre)
-        dW = ops.encoder_wgrad(xo, do).permute(0, 2, 1) if ctx.needs_input_grad[1] else None
-        db = ops.column_sum(dpre.contiguous()) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        dx = ops.encoder_dgrad(do, Wo) if ctx.needs_input_grad[0] else None   # only if activations need grad
-        return dx, dW, db
 
 
 class Encoder(SerializableModule):
@@ -91,7 +72,7 @@ class Encoder(SerializableModule):
     def forward(self, acts_norm, layer="all"):
         if layer != "all":
             return self.forward_layer(acts_norm, layer)
-        return _EncoderFn.apply(acts_norm, self.W, self.b)
+        return torch.ops.clt_hip.encoder(acts_norm, self.W, self.b)          # custom_ops.py: dispatcher op + autograd rule
 
     @torch.no_grad()
     def fold(self, input_standardizer: Standardizer):
@@ -106,45 +87,6 @@ class Encoder(SerializableModule):
 
     def _init_args(self):
         return {"d_acts": self.d_acts, "d_features": self.d_features, "n_layers": self.n_layers}
-
-
-class _PLTDecoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feat, W, b):
-        from .. import ops
-        fo, Wo = _operand(feat), _operand(W)
-        ctx.save_for_backward(fo, Wo)
-        return ops.plt_decoder_fwd(fo, Wo, b)
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        fo, Wo = ctx.saved_tensors
-        go = _operand(g)
-        df = ops.plt_decoder_dgrad(go, Wo) if ctx.needs_input_grad[0] else None
-        dW = ops.plt_decoder_wgrad(fo, go) if ctx.needs_input_grad[1] else None
-        db = ops.column_sum(g.contiguous()) if ctx.needs_input_grad[2] else None
-        return df, dW, db
-
-
-class _CLTDecoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feat, b, *Ws):
-        from .. import ops
-        fo = _operand(feat)
-        Wo = [_operand(w) for w in Ws]
-        ctx.save_for_backward(fo, *Wo)
-        return ops.clt_decoder_fwd(fo, Wo, b)
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        fo, *Wo = ctx.saved_tensors
-        go = _operand(g)
-        df = ops.clt_decoder_dgrad(go, Wo) if ctx.needs_input_grad[0] else None
-        db = ops.column_sum(g.contiguous()) if ctx.needs_input_grad[1] else None
-        dWs = [ops.clt_decoder_wgrad(fo, go, l) if ctx.needs_input_grad[2 + l] else None for l in range(len(Wo))]
-        return (df, db, *dWs)
 
 
 class _DecoderBase(SerializableModule):
@@ -189,7 +131,7 @@ class Decoder(_DecoderBase):
     def forward(self, features, layer="all"):
         if layer != "all":
             return self.forward_layer(features, layer)
-        return _PLTDecoderFn.apply(features, self.W, self.b)
+        return torch.ops.clt_hip.plt_decoder(features, self.W, self.b)
 
     @torch.no_grad()
     def fold(self, output_standardizer: Standardizer):
@@ -236,7 +178,7 @@ class CrosslayerDecoder(_DecoderBase):
     def forward(self, features, layer="all"):
         if layer != "all":
             return self.forward_layer(features, layer)
-        return _CLTDecoderFn.apply(features, self.b, *self.weights())
+        return torch.ops.clt_hip.clt_decoder(features, self.b, self.weights())
 
     @torch.no_grad()
     def fold(self, output_standardizer: Standardizer):

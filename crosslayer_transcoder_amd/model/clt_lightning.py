@@ -102,7 +102,13 @@ class CrossLayerTranscoderModule(_Base):
         self.replacement_model = replacement_model      # eval-time metric objects are accepted and ignored
         self.dead_features = dead_features
         self.learning_rate = learning_rate
-        self.compile = compile                          # torch.compile flag: no-op here (kernels are hand-written)
+        #: reference clt_lightning.py:100-104 (`self = torch.compile(self)` in configure_model — it rebinds a local name, so the
+        #: flag has no effect there).  Here forward() runs a dispatcher-level capture
+        #: of the model (backend "aot_eager": a graph of the registered clt_hip ops, custom_ops.py; there is nothing for a
+        #: code generator to fuse — the kernels are hand-written) and self.model stays unwrapped, so state-dict keys keep the
+        #: reference's names.  The fused training step does not run the module forward and is unaffected.
+        self.compile = compile
+        object.__setattr__(self, "_compiled_model", None)
         self.tokens_till_dead = tokens_till_dead
         self.warmup_steps, self.lr_decay_step, self.lr_decay_factor = warmup_steps, lr_decay_step, lr_decay_factor
         self.compute_dead_features = compute_dead_features
@@ -120,8 +126,7 @@ class CrossLayerTranscoderModule(_Base):
     def configure_model(self):
         """reference clt_lightning.py:100-119 (tensor parallelism when trainer.num_devices > 1): with an initialised
         torch.distributed group of more than one rank, this rank keeps its F/world slice of every feature-axis tensor
-        (parallel.shard_module) and the step's exchange points go through RCCL.  `compile` stays a no-op: the kernels
-        are hand-written."""
+        (parallel.shard_module) and the step's exchange points go through RCCL."""
         import torch.distributed as dist
         if getattr(self, "shard", None) is not None or not (dist.is_available() and dist.is_initialized()):
             return
@@ -130,6 +135,10 @@ class CrossLayerTranscoderModule(_Base):
             shard_module(self, FeatureShard(self.model.encoder.d_features))
 
     def forward(self, acts_norm):
+        if self.compile:
+            if self._compiled_model is None:
+                object.__setattr__(self, "_compiled_model", torch.compile(self.model, backend="aot_eager"))   # (not a submodule)
+            return self._compiled_model(acts_norm)
         return self.model(acts_norm)
 
     # ---- the hot path ---------------------------------------------------------------------------

@@ -2,49 +2,15 @@
 import torch
 import torch.nn as nn
 
+from .. import custom_ops  # noqa: F401  (registers torch.ops.clt_hip.*)
 from .serializable_module import SerializableModule
-
-
-class _ReLUFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        from .. import ops
-        x = x.contiguous()
-        ctx.save_for_backward(x)
-        return ops.relu_fwd(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        (x,) = ctx.saved_tensors
-        return ops.relu_bwd(x, g.contiguous())
 
 
 class ReLU(SerializableModule):
     _ref_module = "crosslayer_transcoder.model.jumprelu"
 
     def forward(self, input, layer=None):
-        return _ReLUFn.apply(input)
-
-
-class _JumpReLUFn(torch.autograd.Function):
-    """fwd: x*[(x>theta)&(x>0)]; bwd: dx = g (0 where x<0), dtheta via the rectangle-window STE
-    (jumprelu.py:31-48), one fused pass + deterministic column reduction."""
-
-    @staticmethod
-    def forward(ctx, x, theta, bandwidth):
-        from .. import ops
-        x = x.contiguous()
-        ctx.save_for_backward(x, theta)
-        ctx.bandwidth = float(bandwidth)
-        return ops.jumprelu_fwd(x, theta)
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        x, theta = ctx.saved_tensors
-        dx, dth = ops.jumprelu_bwd(x, theta, ctx.bandwidth, g.contiguous())
-        return dx, dth, None
+        return torch.ops.clt_hip.relu(input)
 
 
 class JumpReLU(SerializableModule):
@@ -60,7 +26,9 @@ class JumpReLU(SerializableModule):
         self.d_features = d_features
 
     def forward(self, input):
-        return _JumpReLUFn.apply(input, self.theta, self._bandwidth)
+        # fwd: x*[(x>theta)&(x>0)]; bwd: dx = g (0 where x<0), dtheta via the rectangle-window STE (jumprelu.py:31-48),
+        # one fused pass + deterministic column reduction (custom_ops.jumprelu / jumprelu_bwd)
+        return torch.ops.clt_hip.jumprelu(input, self.theta, self._bandwidth)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)

@@ -2,6 +2,7 @@
 config uses — runs on HIP kernels (clt_column_stats_f32 / clt_standardize_f32 / clt_destandardize_f32)."""
 import torch
 
+from .. import custom_ops  # noqa: F401  (registers torch.ops.clt_hip.*)
 from .serializable_module import SerializableModule
 
 
@@ -54,12 +55,11 @@ class _Dimensionwise(Standardizer):
         return self.mean[layer].contiguous(), self.std[layer].contiguous()
 
     def _norm(self, x, layer):
-        from .. import ops
         mean, std = self._sel(layer)
         if layer != "all":                 # [..., d] rows against one layer's statistics
             flat = x.reshape(-1, x.shape[-1])
-            return ops.standardize(flat, mean, std)[0].reshape(x.shape)
-        return ops.standardize(x, mean, std)[0]
+            return torch.ops.clt_hip.standardize(flat, mean, std).reshape(x.shape)
+        return torch.ops.clt_hip.standardize(x, mean, std)
 
 
 class DimensionwiseInputStandardizer(_Dimensionwise):
@@ -75,13 +75,12 @@ class DimensionwiseOutputStandardizer(_Dimensionwise):
 
     def forward(self, batch, layer="all"):
         """De-standardize: batch * std + mean (standardize.py:88-98)."""
-        from .. import ops
         self._require_init()
         mean, std = self._sel(layer)
         if layer != "all":
-            flat = batch.reshape(-1, batch.shape[-1]).contiguous()
-            return ops.destandardize(flat, mean, std).reshape(batch.shape)
-        return ops.destandardize(batch.contiguous(), mean, std)
+            flat = batch.reshape(-1, batch.shape[-1])
+            return torch.ops.clt_hip.destandardize(flat, mean, std).reshape(batch.shape)
+        return torch.ops.clt_hip.destandardize(batch, mean, std)
 
     def standardize(self, mlp_out, layer="all"):
         return self._norm(mlp_out, layer)

@@ -4,29 +4,8 @@ from typing import Union
 
 import torch
 
+from .. import custom_ops  # noqa: F401  (registers torch.ops.clt_hip.*)
 from .serializable_module import SerializableModule
-
-
-class _SelectFn(torch.autograd.Function):
-    """forward = dense features from one of the select kernels; backward = g * [features > 0]
-    (gradient of scatter(relu(gather)))."""
-
-    @staticmethod
-    def forward(ctx, x, mode, k, threshold, e):
-        from .. import ops
-        x = x.contiguous()
-        if mode == "rows":
-            feat = ops.topk_rows(x, k)
-        else:
-            feat = ops.topk_segmented(x, k, mode == "layer", threshold, e)
-        ctx.save_for_backward(feat)
-        return feat
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        (feat,) = ctx.saved_tensors
-        return ops.mask_positive(feat, g.contiguous()), None, None, None, None
 
 
 class TopK(SerializableModule):
@@ -55,12 +34,12 @@ class TopK(SerializableModule):
 class PerLayerTopK(TopK):
     def _training_forward(self, features):
         self._check(features)
-        return _SelectFn.apply(features, "rows", self.k, None, 0.0)
+        return torch.ops.clt_hip.topk_rows(features, self.k)       # backward = g * [features > 0] (scatter(relu(gather)))
 
     @torch.no_grad()
     def _inference_forward(self, features, layer):
         shp = features.shape
-        out = _SelectFn.apply(features.reshape(-1, 1, shp[-1]), "rows", self.k, None, 0.0)
+        out = torch.ops.clt_hip.topk_rows(features.reshape(-1, 1, shp[-1]), self.k)
         return out.reshape(shp)
 
 
@@ -71,16 +50,19 @@ class _EmaTopK(TopK):
         self._check(features)
         if self.k > 0 and self.e is None:
             raise TypeError("BatchTopK needs `e` (threshold EMA rate) for training")
-        # the reference rebinds `self.threshold` to a fresh tensor each step (topk.py:95,132); the kernel
-        # updates the registered buffer in place, which is state-dict-equivalent and allocation-free
-        return _SelectFn.apply(features, "layer" if self._per_layer else "batch", self.k,
-                               self.threshold if self.k > 0 else None, self.e or 0.0)
+        # the reference rebinds `self.threshold` to a fresh tensor each step (topk.py:95,132); here the registered buffer is
+        # overwritten with the op's updated copy, which is state-dict-equivalent
+        feat, thr = torch.ops.clt_hip.batch_topk(features, self.k, self._per_layer, self.threshold if self.k > 0 else None,
+                                                 float(self.e or 0.0))
+        if self.k > 0:
+            with torch.no_grad():
+                self.threshold.copy_(thr)
+        return feat
 
     @torch.no_grad()
     def _inference_forward(self, features, layer):
-        from .. import ops
         thr = self.threshold[layer:layer + 1].contiguous() if self._per_layer else self.threshold
-        return ops.threshold_fwd(features.contiguous(), thr, False, 1)
+        return torch.ops.clt_hip.threshold(features, thr)
 
 
 class BatchTopK(_EmaTopK):

@@ -128,3 +128,24 @@ def test_own_debug_config_builds_module_and_datamodule():
     from crosslayer_transcoder_amd import get_precision, set_precision
     assert get_precision() == "bf16"
     set_precision("32")
+
+
+def test_forward_ops_are_registered_with_the_dispatcher():
+    """custom_ops.py: the module forward's operators exist as torch.ops.clt_hip.* with schemas, fake-tensor rules (shape
+    propagation without a device) and no CPU kernel (there is no CPU fallback)."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from crosslayer_transcoder_amd import custom_ops as C
+    for name in C.REGISTERED:
+        op = getattr(torch.ops.clt_hip, name).default
+        assert op._schema.name == f"clt_hip::{name}"
+    with FakeTensorMode():
+        xs, W, b = torch.empty(8, 3, 16, device="cuda"), torch.empty(3, 16, 32, device="cuda"), torch.empty(3, 32, device="cuda")
+        pre = torch.ops.clt_hip.encoder(xs, W, b)
+        assert pre.shape == (8, 3, 32) and pre.dtype == torch.float32
+        feat, thr = torch.ops.clt_hip.batch_topk(pre, 4, True, torch.empty(3, device="cuda"), 0.1)
+        r = torch.ops.clt_hip.clt_decoder(feat, torch.empty(3, 16, device="cuda"), [torch.empty(l + 1, 32, 16, device="cuda") for l in range(3)])
+        assert r.shape == (8, 3, 16) and thr.shape == (3,)
+    import pytest
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.clt_hip.relu(torch.zeros(4, 4))
