@@ -189,7 +189,7 @@ def parse_args():
                          "data, the ~10 %% of BASELINE.md config 3; 3 -> 0.3 %%)")
     ap.add_argument("--nonlinearity", default="batchtopk", choices=["batchtopk", "topk", "relu", "jumprelu"])
     ap.add_argument("--decoder", default="clt", choices=["clt", "plt"])
-    ap.add_argument("--precision", default="bf16-mixed")
+    ap.add_argument("--precision", default="bf16-mixed", help="bf16-mixed | 16-mixed (fp16 operands + dynamic loss scaling) | 32")
     ap.add_argument("--api", default="training_step", choices=["training_step", "fused_train_step"],
                     help="training_step: the Lightning-facing contract (manual optimisation, optimizers()/lr_schedulers()); "
                          "fused_train_step: the same step called directly")
@@ -335,7 +335,7 @@ def main():
         "metric": "activation tokens/sec (fwd+bwd+Adam), GPT-2 CLT 32k feats, 1/2/4/8 MI355X",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if args.precision.startswith("bf16") else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp16": "f16", "32": "f32"}[cta.get_precision()], "data": "synthetic",
         "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if args.shard_rehearsal else 0),
         "config": {"workload": f"gpt2-small {args.decoder.upper()} {args.nonlinearity}"
                                + (f"(k={args.k})" if args.nonlinearity in ("batchtopk", "topk") else "")

@@ -73,6 +73,8 @@ SIGNATURES = {
     "clt_select_rows_sharded_exchange_info": (SZ, [I, I, I, I, I, I]),
     "clt_select_rows_sharded_f32": (I, [I, I, I, I, I, P, P, I, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_gemm_bf16_nt_kseg": (I, [P, P, P, I, I, I, I, L, L, L, P, I, P]),
+    "clt_set_loss_scaling": (I, [I, F32, P]),
+    "clt_operand_format": (I, []),
     "clt_gemm_bf16_nt_out16": (I, [P, P, P, I, I, I, L, L, L, I, L, L, L, P, L, P]),
     "clt_gemm_bf16_nt_kseg_out16": (I, [P, P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
@@ -90,7 +92,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CltError(RuntimeError):

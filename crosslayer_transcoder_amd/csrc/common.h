@@ -18,7 +18,6 @@ static inline bool diag_env(const char* name) { return getenv(name) != nullptr; 
 static inline bool diag_env(const char*) { return false; }
 #endif
 
-// fp32 -> bf16, round to nearest even (NaN stays NaN through the compiler's cvt on gfx950).
 // fp32 -> bf16, round to nearest even, by gfx950's packed conversion (v_cvt_pk_bf16_f32): lo in bits 0..15, hi in 16..31
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     typedef __bf16 clt_bf16x2 __attribute__((ext_vector_type(2)));
@@ -28,6 +27,40 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)pack_bf16x2(f, 0.0f); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// ---- 16-bit operand format and loss-scaling state (clt_set_loss_scaling, reference: Lightning precision "16-mixed" =
+// torch.autocast(float16) + GradScaler around clt_lightning.py:290-312) ------------------------------------------------
+// Process-wide library state, like a BLAS math mode.  The host copy (clt_host_state) picks the MFMA instantiation of the
+// GEMMs; the kernels that convert to / from the 16-bit operand format or apply Adam read the copies in constant memory of
+// their own translation unit (CLT_DEFINE_TU_STATE_SETTER), on the device that was current when the state was set.
+struct CltState {
+    int fp16;             // 0: bf16 operands (default), 1: fp16 operands
+    float grad_unscale;   // Adam multiplies every gradient by this (1 / loss scale; 1 when no scaling)
+    int* inf_flag;        // device int: set to 1 by any fp32 -> fp16 conversion that yields inf / NaN; Adam kernels leave
+                          // parameters and moments untouched when it is set (GradScaler's skipped step).  nullptr: off
+};
+extern CltState clt_host_state;
+__attribute__((unused)) static __constant__ CltState clt_dev_state = {0, 1.0f, nullptr};
+#define CLT_DEFINE_TU_STATE_SETTER(fn) \
+    int fn(const CltState* s) { return hipMemcpyToSymbol(HIP_SYMBOL(clt_dev_state), s, sizeof(CltState)) == hipSuccess ? CLT_OK : CLT_ERR_LAUNCH; }
+
+// fp32 -> fp16, round to nearest even; an inf / NaN result raises the loss scaler's flag
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    typedef _Float16 clt_f16x2 __attribute__((ext_vector_type(2)));
+    typedef float clt_f32x2 __attribute__((ext_vector_type(2)));
+    const clt_f32x2 v = {lo, hi};
+    const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, clt_f16x2));
+    if ((((u & 0x7c00u) == 0x7c00u) || ((u & 0x7c000000u) == 0x7c000000u)) && clt_dev_state.inf_flag) *clt_dev_state.inf_flag = 1;
+    return u;
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// 16-bit operand conversions with the format as a template parameter (kernels are instantiated per format and picked at
+// launch from clt_host_state.fp16: the hot loops must not pay a per-element select)
+template <bool F16> __device__ __forceinline__ float cvt16(uint16_t h) { return F16 ? f16_to_f32(h) : bf16_to_f32(h); }
+template <bool F16> __device__ __forceinline__ uint32_t pack16(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+template <bool F16> __device__ __forceinline__ uint16_t to16(float f) { return (uint16_t)pack16<F16>(f, 0.0f); }
+// Adam kernels: true when the step is to be skipped (an overflow was seen while this step's gradients were formed)
+__device__ __forceinline__ bool clt_skip_update() { return clt_dev_state.inf_flag && *clt_dev_state.inf_flag != 0; }
 
 // Order-preserving key of an fp32 value (ascending key == ascending value; -0 folded onto +0).
 __device__ __forceinline__ uint32_t f32_key(float f) {
@@ -75,3 +108,5 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
                               hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false);
+int clt_internal_set_state_elementwise(const CltState* s);
+int clt_internal_set_state_sparse(const CltState* s);

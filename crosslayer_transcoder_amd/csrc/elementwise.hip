@@ -29,7 +29,7 @@ __global__ void column_stats_kernel(const float* __restrict__ x, long rs, int ro
     stdv[j] = sd < 1e-8f ? 1e-8f : sd;    // clamp_(min=1e-8); nan stays nan as in torch.clamp
 }
 
-template <bool VEC>
+template <bool VEC, bool F16>
 __global__ void standardize_kernel(const float* __restrict__ x, long rs, const float* __restrict__ mean,
                                    const float* __restrict__ stdv, int rows, int n, float* __restrict__ o32,
                                    uint16_t* __restrict__ o16) {
@@ -54,9 +54,9 @@ __global__ void standardize_kernel(const float* __restrict__ x, long rs, const f
         }
         if (o16) {
             if (VEC) {
-                ushort4 h; h.x = f32_to_bf16(v[0]); h.y = f32_to_bf16(v[1 % W]); h.z = f32_to_bf16(v[2 % W]); h.w = f32_to_bf16(v[3 % W]);
+                ushort4 h; h.x = to16<F16>(v[0]); h.y = to16<F16>(v[1 % W]); h.z = to16<F16>(v[2 % W]); h.w = to16<F16>(v[3 % W]);
                 *reinterpret_cast<ushort4*>(o16 + o) = h;
-            } else o16[o] = f32_to_bf16(v[0]);
+            } else o16[o] = to16<F16>(v[0]);
         }
     }
 }
@@ -174,6 +174,7 @@ __global__ void mse_kernel(const float* __restrict__ r, const float* __restrict_
 // One pass instead of mse + cast + column_sum, and no fp32 gradient tensor.  Block = 64 rows x 256 columns (a wave per
 // row, 4 columns per lane); part_c: [gridDim.y][n] column partials, part_l: [gridDim.x * gridDim.y] loss partials.
 constexpr int MF_R = 64;
+template <bool F16>
 __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
                                                               const float* __restrict__ mean, const float* __restrict__ stdv, int rows,
                                                               int n, float gs, uint16_t* __restrict__ g16, float* __restrict__ part_c,
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
         cs[0] += g0; cs[1] += g1; cs[2] += g2; cs[3] += g3;
         acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
         *reinterpret_cast<uint2*>(g16 + (long)row * n + col) =
-            make_uint2((uint32_t)f32_to_bf16(g0) | ((uint32_t)f32_to_bf16(g1) << 16), (uint32_t)f32_to_bf16(g2) | ((uint32_t)f32_to_bf16(g3) << 16));
+            make_uint2(pack16<F16>(g0, g1), pack16<F16>(g2, g3));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) red[w][4 * tx + k] = cs[k];
@@ -356,12 +357,14 @@ __global__ void threshold_fwd_kernel(const float* __restrict__ x, const float* _
     }
 }
 
+template <bool F16>
 __global__ void cast_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = f32_to_bf16(in[i]);
+        out[i] = to16<F16>(in[i]);
 }
 
 // 64x64 tile transpose through LDS: in [rows][cols] (ld_in) -> out [cols][rows] (ld_out), bf16
+template <bool F16>
 __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, uint16_t* __restrict__ out, long ldo, int rows,
                                       int cols, long s_in, long s_out) {
     __shared__ float tile[64][65];
@@ -371,7 +374,7 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
         tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(long)(r0 + r) * ldi + c0 + tx] : 0.0f;
     __syncthreads();
     for (int c = ty; c < 64; c += 4)
-        if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = f32_to_bf16(tile[tx][c]);
+        if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = to16<F16>(tile[tx][c]);
 }
 
 // ---- fused tile passes of the dense bf16 regime (JumpReLU / ReLU modules) ---------------------------------------
@@ -385,10 +388,11 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, long ldi, ui
 // groups x 8 columns of a wave-instruction fall on 64 distinct banks).
 constexpr int FT_R = 64, FT_C = 256, FT_PITCH = 258;      // pitch in dwords
 
+template <bool F16>
 __device__ __forceinline__ void ft_store_pair(uint32_t (*tile)[FT_PITCH], int p, int tx, const float a[4], const float b[4]) {
     uint2* q = reinterpret_cast<uint2*>(&tile[p][4 * tx]);
-    q[0] = make_uint2(pack_bf16x2(a[0], b[0]), pack_bf16x2(a[1], b[1]));
-    q[1] = make_uint2(pack_bf16x2(a[2], b[2]), pack_bf16x2(a[3], b[3]));
+    q[0] = make_uint2(pack16<F16>(a[0], b[0]), pack16<F16>(a[1], b[1]));
+    q[1] = make_uint2(pack16<F16>(a[2], b[2]), pack16<F16>(a[3], b[3]));
 }
 // transposed write-out of a [64][256] bf16 tile: column c gets 64 consecutive rows (128 B); 8 threads x 16 B per column
 __device__ __forceinline__ void ft_write_transposed(const uint32_t (*tile)[FT_PITCH], uint16_t* __restrict__ outT, long c0, int r0,
@@ -413,7 +417,7 @@ template <bool BF> __device__ __forceinline__ float4 act_load4(const void* __res
 }
 
 // grid (ceil(n/256), ceil(rows/64)); rows % 8 == 0, n % 4 == 0
-template <bool XB>
+template <bool XB, bool F16>
 __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta, int rows,
                                                                 int n, uint16_t* __restrict__ feat, uint16_t* __restrict__ featT,
                                                                 uint8_t* __restrict__ fired) {
@@ -446,9 +450,9 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 #pragma unroll
                 for (int k = 0; k < 4; ++k) any[k] |= f[e][k] > 0.0f;
                 if (cin && row + e < rows)
-                    *reinterpret_cast<uint2*>(feat + (long)(row + e) * n + col) = make_uint2(pack_bf16x2(f[e][0], f[e][1]), pack_bf16x2(f[e][2], f[e][3]));
+                    *reinterpret_cast<uint2*>(feat + (long)(row + e) * n + col) = make_uint2(pack16<F16>(f[e][0], f[e][1]), pack16<F16>(f[e][2], f[e][3]));
             }
-            ft_store_pair(tile, pr, tx, f[0], f[1]);
+            ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
         }
     }
     if (cin) {                                         // fired[] is zeroed by the host wrapper; equal-value stores may race
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 // squared row norms sq[b*rows + r] (+)= sum_j W^2 (dec_norms of the sparsity penalty, clt_lightning.py:438-448) — three
 // separate passes over 7.85 GB of decoder weights otherwise.  grid (ceil(rows/64), nb); a block walks the column tiles of
 // its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
+template <bool F16>
 __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
                                                           uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate) {
     __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
@@ -491,9 +496,9 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
                 acc[2 * i + e] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 f[e][0] = v.x; f[e][1] = v.y; f[e][2] = v.z; f[e][3] = v.w;
                 if (in && op)
-                    *reinterpret_cast<uint2*>(op + (long)(row + e) * n + col) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    *reinterpret_cast<uint2*>(op + (long)(row + e) * n + col) = make_uint2(pack16<F16>(v.x, v.y), pack16<F16>(v.z, v.w));
             }
-            ft_store_pair(tile, pr, tx, f[0], f[1]);
+            ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
         }
         if (opT) {
             __syncthreads();
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 
 // grid (ceil(n/256), ceil(rows/256)): a block walks 4 row tiles of its 256 columns, keeping the column partial sums in
 // registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
-template <bool XB, bool GB, bool TANH>
+template <bool XB, bool GB, bool TANH, bool F16>
 __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
                                                                  const float* __restrict__ sq, const void* __restrict__ dfm, float bw,
                                                                  float lamB, float c, float coefBL,
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __r
                         dpv[e][k] = dp;
                     }
                 }
-                ft_store_pair(tile, pr, tx, dpv[0], dpv[1]);
+                ft_store_pair<F16>(tile, pr, tx, dpv[0], dpv[1]);
             }
         }
         s_t += (double)f_t; s_w += (double)f_w; s_p += (double)f_p;
@@ -668,13 +673,19 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, lon
 }
 
 // ---- K13 --------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n4, long n, float lr, float omb1, float b2, float omb2, float eps, float wd, int adamw,
                             float step_size, float inv_sqrt_bc2, uint16_t* __restrict__ sh, const float* __restrict__ rdn,
                             const float* __restrict__ rsq, int rlen) {
     // optional per-row gradient term g += (rdn[row] / sqrt(rsq[row])) * p, row = element / rlen: the gradient that reaches
-    // the decoder weights through dec_norms (clt_lightning.py:438-446), folded in here instead of a pass of its own
+    // the decoder weights through dec_norms (clt_lightning.py:438-446), folded in here instead of a pass of its own.
+    // Loss scaling (clt_set_loss_scaling): gradients arrive multiplied by the loss scale and are unscaled here; a step
+    // whose gradients overflowed is skipped as a whole (GradScaler.step)
+    if (clt_skip_update()) return;
+    const float unscale = clt_dev_state.grad_unscale;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= unscale;
         if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
         mm = mm + (gg - mm) * omb1;
         vv = vv * b2 + omb2 * gg * gg;
@@ -688,8 +699,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         if (rdn) { const long row = i * 4 / rlen; const float cf = rdn[row] / sqrtf(rsq[row]); G.x += cf * P.x; G.y += cf * P.y; G.z += cf * P.z; G.w += cf * P.w; }
         upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
         reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
-        if (sh) { ushort4 h; h.x = f32_to_bf16(P.x); h.y = f32_to_bf16(P.y); h.z = f32_to_bf16(P.z); h.w = f32_to_bf16(P.w);
-                  reinterpret_cast<ushort4*>(sh)[i] = h; }
+        if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack16<F16>(P.x, P.y), pack16<F16>(P.z, P.w));
     }
     for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
         float P = p[i], M = m[i], V = v[i];
@@ -697,15 +707,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         if (rdn) { const long row = i / rlen; G += rdn[row] / sqrtf(rsq[row]) * P; }
         upd(P, G, M, V);
         p[i] = P; m[i] = M; v[i] = V;
-        if (sh) sh[i] = f32_to_bf16(P);
+        if (sh) sh[i] = to16<F16>(P);
     }
 }
 }  // namespace
 
+CltState clt_host_state = {0, 1.0f, nullptr};
+CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
+
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 2; }
+int clt_abi_version(void) { return 3; }
+
+int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
+    if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;
+    // (work already queued read the old state: drain it first; the state changes at configuration time and when the loss
+    // scale moves — every growth interval, or after an overflow)
+    if (hipDeviceSynchronize() != hipSuccess) return CLT_ERR_LAUNCH;
+    const CltState s = {fp16_operands ? 1 : 0, 1.0f / loss_scale, reinterpret_cast<int*>(found_inf)};
+    int rc = clt_internal_set_state_elementwise(&s);
+    if (rc == CLT_OK) rc = clt_internal_set_state_sparse(&s);
+    if (rc == CLT_OK) clt_host_state = s;
+    return rc;
+}
+int clt_operand_format(void) { return clt_host_state.fp16; }
 
 int clt_column_stats_f32(const float* x, long rs, int rows, int n, float* mean, float* stdv, void* st) {
     if (rows <= 0 || n <= 0 || rs < n) return CLT_ERR_SHAPE;
@@ -719,8 +745,10 @@ int clt_standardize_f32(const float* x, long rs, const float* mean, const float*
                      (!o32 || aligned16(o32)) && (!o16 || (reinterpret_cast<uintptr_t>(o16) & 7) == 0);
     const long work = (long)rows * n / (vec ? 4 : 1);
     const int nb = blocks_for(work, TPB);
-    if (vec) hipLaunchKernelGGL((standardize_kernel<true>), dim3(nb), dim3(TPB), 0, as_stream(st), x, rs, mean, stdv, rows, n, o32, o16);
-    else hipLaunchKernelGGL((standardize_kernel<false>), dim3(nb), dim3(TPB), 0, as_stream(st), x, rs, mean, stdv, rows, n, o32, o16);
+#define STD(V_, F_) hipLaunchKernelGGL((standardize_kernel<V_, F_>), dim3(nb), dim3(TPB), 0, as_stream(st), x, rs, mean, stdv, rows, n, o32, o16)
+    if (clt_host_state.fp16) { if (vec) STD(true, true); else STD(false, true); }
+    else { if (vec) STD(true, false); else STD(false, false); }
+#undef STD
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_destandardize_f32(const float* r, const float* mean, const float* stdv, int rows, int n, float* out, void* st) {
@@ -796,7 +824,9 @@ static int mse_bf16_colsum_impl(const float* r, const float* y, long yrs, const 
     const int chunks = (rows + MF_R - 1) / MF_R, ctiles = (n + 255) / 256;
     double* part_l = (double*)ws;
     float* part_c = (float*)(part_l + (size_t)chunks * ctiles);
-    hipLaunchKernelGGL(mse_bf16_colsum_kernel, dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
+    if (clt_host_state.fp16) hipLaunchKernelGGL((mse_bf16_colsum_kernel<true>), dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
+                       part_c, part_l, layer_rows);
+    else hipLaunchKernelGGL((mse_bf16_colsum_kernel<false>), dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
                        part_c, part_l, layer_rows);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)part_l, chunks * ctiles, 1, loss_sum);
     const int groups = layer_rows > 0 ? rows / layer_rows : 1;        // column sums per layer: colsum is [layers][n]
@@ -903,8 +933,11 @@ int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int row
     if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta))) return CLT_ERR_ALIGN;
     if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
     const dim3 grid((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R);
-    if (x_bf16) hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel<true>, grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired);
-    else hipLaunchKernelGGL(jumprelu_fwd_bf16_kernel<false>, grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired);
+#define JF(XB_, F_) hipLaunchKernelGGL((jumprelu_fwd_bf16_kernel<XB_, F_>), grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired)
+    if (clt_host_state.fp16) { if (x_bf16) return CLT_ERR_SHAPE; JF(false, true); }        // (16-bit activations: bf16 operand mode only)
+    else if (x_bf16) JF(true, false);
+    else JF(false, false);
+#undef JF
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n) {
@@ -920,10 +953,14 @@ int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, co
     const int gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C, gc = (n + TPB - 1) / TPB;
     float* part = (float*)ws;
     double* ps = (double*)((char*)ws + align_up((size_t)3 * gy * n * sizeof(float), 16));
-#define JL2(XB_, GB_, TH_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, \
-                                             dfm, bw, lamB, c, coefBL, dpreT, part, ps, rows, n)
-#define JL(XB_, GB_) do { if (use_tanh) JL2(XB_, GB_, true); else JL2(XB_, GB_, false); } while (0)
-    if (x_bf16) { if (dfm_bf16) JL(true, true); else JL(true, false); }
+#define JL2(XB_, GB_, TH_, F_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_, F_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, \
+                                                 dfm, bw, lamB, c, coefBL, dpreT, part, ps, rows, n)
+#define JL(XB_, GB_) do { if (use_tanh) JL2(XB_, GB_, true, false); else JL2(XB_, GB_, false, false); } while (0)
+    if (clt_host_state.fp16) {                                  // (16-bit activations: bf16 operand mode only)
+        if (x_bf16 || dfm_bf16) return CLT_ERR_SHAPE;
+        if (use_tanh) JL2(false, false, true, true); else JL2(false, false, false, true);
+    }
+    else if (x_bf16) { if (dfm_bf16) JL(true, true); else JL(true, false); }
     else { if (dfm_bf16) JL(false, true); else JL(false, false); }
 #undef JL2
 #undef JL
@@ -970,13 +1007,15 @@ int clt_threshold_fwd_f32(const float* x, const float* thr, int per_layer, float
 }
 int clt_cast_bf16(const float* in, uint16_t* out, long n, void* st) {
     if (n <= 0) return CLT_ERR_SHAPE;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), in, out, n);
+    if (clt_host_state.fp16) hipLaunchKernelGGL((cast_bf16_kernel<true>), dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), in, out, n);
+    else hipLaunchKernelGGL((cast_bf16_kernel<false>), dim3(blocks_for(n, TPB)), dim3(TPB), 0, as_stream(st), in, out, n);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, uint16_t* opT, float* sq, int accumulate, void* st) {
     if (nb <= 0 || rows <= 0 || n <= 0 || !W) return CLT_ERR_SHAPE;
     if (rows % 8 || n % 4 || !aligned16(W) || (op && !aligned16(op)) || (opT && !aligned16(opT))) return CLT_ERR_ALIGN;
-    hipLaunchKernelGGL(weight_prep_kernel, dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
+    if (clt_host_state.fp16) hipLaunchKernelGGL((weight_prep_kernel<true>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
+    else hipLaunchKernelGGL((weight_prep_kernel<false>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
@@ -984,7 +1023,9 @@ int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, 
 int clt_cast_transpose_bf16(const float* in, long ldi, uint16_t* out, long ldo, int rows, int cols, int batch, long s_in,
                             long s_out, void* st) {
     if (rows <= 0 || cols <= 0 || batch <= 0 || ldi < cols || ldo < rows) return CLT_ERR_SHAPE;
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(TPB), 0, as_stream(st),
+    if (clt_host_state.fp16) hipLaunchKernelGGL((cast_transpose_kernel<true>), dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(TPB), 0, as_stream(st),
+                       in, ldi, out, ldo, rows, cols, s_in, s_out);
+    else hipLaunchKernelGGL((cast_transpose_kernel<false>), dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(TPB), 0, as_stream(st),
                        in, ldi, out, ldo, rows, cols, s_in, s_out);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
@@ -1004,7 +1045,9 @@ int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr
     const float step_size = (float)(lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
     const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow || (reinterpret_cast<uintptr_t>(shadow) & 7) == 0);
     const long n4 = (vec && (!row_dnorm || row_len % 4 == 0)) ? n / 4 : 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
+    if (clt_host_state.fp16) hipLaunchKernelGGL((adam_kernel<true>), dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
+                       (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow, row_dnorm, row_sq, row_len);
+    else hipLaunchKernelGGL((adam_kernel<false>), dim3(blocks_for(n4 > 0 ? n4 : n, TPB, 16384)), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
                        (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow, row_dnorm, row_sq, row_len);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }

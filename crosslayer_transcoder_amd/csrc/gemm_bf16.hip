@@ -11,6 +11,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 8;   // PITCH in bf16 elements (80 B)
@@ -54,7 +55,8 @@ __device__ __forceinline__ void store_tile(uint16_t* __restrict__ S, int tid, co
     }
 }
 
-template <bool TA, bool TB, bool VEC>
+// F16: the operands are fp16 instead of bf16 (clt_set_loss_scaling) — same tiles, the f16 MFMA of the same shape
+template <bool TA, bool TB, bool VEC, bool F16>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                         float* __restrict__ C, int M, int N, int K, long lda, long ldb,
                                                         long ldc, long sA, long sB, long sC, const float* __restrict__ bias,
@@ -101,7 +103,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    if constexpr (F16)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mi]), __builtin_bit_cast(f16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -129,13 +134,15 @@ template <bool VEC>
 int launch(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int tA,
            int tB, int batch, long sA, long sB, long sC, const float* bias, long sBias, int acc, hipStream_t st) {
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch), block(256);
-#define GO(TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, VEC>), grid, block, 0, st, A, B, C, M, N, K, lda, \
-                                        ldb, ldc, sA, sB, sC, bias, sBias, acc)
+#define GO2(TA_, TB_, F_) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, VEC, F_>), grid, block, 0, st, A, B, C, M, N, K, lda, \
+                                             ldb, ldc, sA, sB, sC, bias, sBias, acc)
+#define GO(TA_, TB_) do { if (clt_host_state.fp16) GO2(TA_, TB_, true); else GO2(TA_, TB_, false); } while (0)
     if (!tA && !tB) GO(false, false);
     else if (!tA && tB) GO(false, true);
     else if (tA && !tB) GO(true, false);
     else GO(true, true);
 #undef GO
+#undef GO2
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -15,6 +15,7 @@
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (kernel experiments are built as variants of this file — `make variant V=n` defines GEMM_VARIANT — and compared in one
@@ -57,7 +58,8 @@ struct SelEpi {
     int seg_per_batch;            // 1: segment = batch index (per-layer selection); 0: one segment
 };
 
-template <int EPI>
+// F16: fp16 operands (clt_set_loss_scaling) instead of bf16 — the same kernel around v_mfma_f32_16x16x32_f16
+template <int EPI, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
@@ -227,7 +229,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[ks][n], acc[m][n], 0, 0, 0);
+                        if constexpr (F16)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[m]), __builtin_bit_cast(f16x8, fa[ks][n]), acc[m][n], 0, 0, 0);
+                        else
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[m], fa[ks][n], acc[m][n], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -420,7 +425,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                               hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
     // bf16 result (C is then a bf16 array; ldc / sC in bf16 elements): 8-column alignment, no accumulate, no groups
-    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
+    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8 || clt_host_state.fp16)) return 1;
     const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
@@ -430,6 +435,15 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     if (nblk > 0x7fffffffL) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (clt_host_state.fp16) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<0, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
+                           lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
+                           gemm_diag(), SelEpi{}, Bseg, kts, grp);
+        CLT_LAUNCH_CHECK();
+        return CLT_OK;
+    }
     if (out16) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
@@ -495,6 +509,15 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
     const long nblk = (long)tilesA * tilesB * batch;
     if (nblk > 0x7fffffffL) return 1;
+    if (clt_host_state.fp16) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
+                           (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(),
+                           SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0, (const GemmGroup*)nullptr);
+        CLT_LAUNCH_CHECK();
+        return CLT_OK;
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,

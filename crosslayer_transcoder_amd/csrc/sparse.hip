@@ -16,12 +16,14 @@
 #include "lists_common.h"
 
 namespace {
+
 constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------
 // forward gather: one wave per (token, target layer)
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool VEC, bool BF>
+// F16: the 16-bit rows are fp16 instead of bf16 (clt_set_loss_scaling)
+template <int NT, bool VEC, bool BF, bool F16 = false>
 __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
                                                                  const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int L, int F,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             float4 x;
-                            if constexpr (BF) x = make_float4(bf16_to_f32(r[u][t].x), bf16_to_f32(r[u][t].y), bf16_to_f32(r[u][t].z), bf16_to_f32(r[u][t].w));
+                            if constexpr (BF) x = make_float4(cvt16<F16>(r[u][t].x), cvt16<F16>(r[u][t].y), cvt16<F16>(r[u][t].z), cvt16<F16>(r[u][t].w));
                             else x = r[u][t];
                             acc[t][0] += v[u] * x.x; acc[t][1 % W] += v[u] * x.y; acc[t][2 % W] += v[u] * x.z; acc[t][3 % W] += v[u] * x.w;
                         }
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             const int o = t * 64 + lane;
-                            if (o < d) acc[t][0] += v[u] * (BF ? bf16_to_f32(Wh[ro[u] + o]) : Wl[ro[u] + o]);
+                            if (o < d) acc[t][0] += v[u] * (BF ? cvt16<F16>(Wh[ro[u] + o]) : Wl[ro[u] + o]);
                         }
                 }
             }
@@ -126,7 +128,7 @@ struct RowPassArgs {
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
 // 16-byte lanes).  CW > 1 (long rows, e.g. d = 4096): one row per block, wave c owns the c-th 1024-float chunk —
 // keeps the per-lane state at NT = 4 (high occupancy) and combines the per-entry dots through LDS in wave order.
-template <int NT, bool VEC, int CW>
+template <int NT, bool VEC, int CW, bool F16 = false>
 __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
     constexpr int W = VEC ? 4 : 1;
     __shared__ float shdot[2][CW];
@@ -192,11 +194,11 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
                         float4 s;
                         if (a.src_bf16) {
                             const ushort4 h = *reinterpret_cast<const ushort4*>(srowh + o);
-                            s = make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+                            s = make_float4(cvt16<F16>(h.x), cvt16<F16>(h.y), cvt16<F16>(h.z), cvt16<F16>(h.w));
                         } else s = *reinterpret_cast<const float4*>(srow + o);
                         g[t][0] += cv * s.x; g[t][1 % W] += cv * s.y; g[t][2 % W] += cv * s.z; g[t][3 % W] += cv * s.w;
                         dot += s.x * wv[t][0] + s.y * wv[t][1 % W] + s.z * wv[t][2 % W] + s.w * wv[t][3 % W];
-                    } else { const float s = a.src_bf16 ? bf16_to_f32(srowh[o]) : srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
+                    } else { const float s = a.src_bf16 ? cvt16<F16>(srowh[o]) : srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
                 }
             }
             csum += cv;
@@ -249,13 +251,18 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
         }
         return;
     }
+    // loss scaling (clt_set_loss_scaling): the gathered sources carry the loss scale, the gradient is unscaled here; a step
+    // whose gradients overflowed leaves weights, moments and shadow untouched (the dots and column sums above are still
+    // written: the later passes of this step run, and skip likewise)
+    if (clt_skip_update()) return;
+    const float unscale = clt_dev_state.grad_unscale;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int o = cb + (t * 64 + lane) * W;
         if (o >= a.d) continue;
 #pragma unroll
         for (int c = 0; c < W; ++c) {
-            float gg = g[t][c], pp = wv[t][c];
+            float gg = g[t][c] * unscale, pp = wv[t][c];
             if (a.wd != 0.0f) { if (a.adamw) pp *= (1.0f - a.lr * a.wd); else gg += a.wd * pp; }
             mm[t][c] = mm[t][c] + (gg - mm[t][c]) * a.omb1;
             vv[t][c] = vv[t][c] * a.b2 + a.omb2 * gg * gg;
@@ -266,11 +273,10 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
             *reinterpret_cast<float4*>(a.W + ro + o) = make_float4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
             *reinterpret_cast<float4*>(a.m + ro + o) = make_float4(mm[t][0], mm[t][1 % W], mm[t][2 % W], mm[t][3 % W]);
             *reinterpret_cast<float4*>(a.v + ro + o) = make_float4(vv[t][0], vv[t][1 % W], vv[t][2 % W], vv[t][3 % W]);
-            if (a.shadow) { ushort4 h; h.x = f32_to_bf16(wv[t][0]); h.y = f32_to_bf16(wv[t][1 % W]); h.z = f32_to_bf16(wv[t][2 % W]); h.w = f32_to_bf16(wv[t][3 % W]);
-                            *reinterpret_cast<ushort4*>(a.shadow + ro + o) = h; }
+            if (a.shadow) *reinterpret_cast<uint2*>(a.shadow + ro + o) = make_uint2(pack16<F16>(wv[t][0], wv[t][1 % W]), pack16<F16>(wv[t][2 % W], wv[t][3 % W]));
         } else {
             a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[t][0]; a.v[ro + o] = vv[t][0];
-            if (a.shadow) a.shadow[ro + o] = f32_to_bf16(wv[t][0]);
+            if (a.shadow) a.shadow[ro + o] = (uint16_t)pack16<F16>(wv[t][0], 0.0f);
         }
     }
 }
@@ -305,6 +311,8 @@ __global__ void list_gate_kernel(const uint32_t* __restrict__ total, uint32_t ca
 }
 
 }  // namespace
+
+CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_sparse)
 
 // dispatch on the number of 64-lane chunks a row needs
 #define DISPATCH_NT(KERNEL, GRID, STREAM, D, VECOK, ...)                                                         \
@@ -397,7 +405,10 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
     const bool vec = d % 4 == 0 && aligned16(out) && out_tok_stride % 4 == 0 && out_layer_stride % 4 == 0;
 #define FWDK(NT_, VEC_)                                                                                              \
     do {                                                                                                              \
-        if (w_bf16) hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true>), dim3(B), dim3(TPB), 0, as_stream(stp),  \
+        if (w_bf16 && clt_host_state.fp16)                                                                            \
+            hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true, true>), dim3(B), dim3(TPB), 0, as_stream(stp), \
+                               row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
+        else if (w_bf16) hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true>), dim3(B), dim3(TPB), 0, as_stream(stp),  \
                                        row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
         else hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, false>), dim3(B), dim3(TPB), 0, as_stream(stp), \
                                 row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
@@ -446,7 +457,11 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     hipStream_t st = as_stream(stp);
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);   // 64-lane iterations a whole row needs
     const dim3 g4((rows + 3) / 4), g1(rows);
-#define RP(NT_, VEC_, CW_, GRID_) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a)
+#define RP(NT_, VEC_, CW_, GRID_)                                                                                          \
+    do {                                                                                                                    \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_, true>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a); \
+        else hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a);       \
+    } while (0)
     if (vec) {
         if (chunks <= 1) RP(1, true, 1, g4);
         else if (chunks <= 2) RP(2, true, 1, g4);

@@ -19,7 +19,10 @@ _DEV = "cuda"
 def _operand(t: Tensor) -> Tensor:
     """fp32 tensor -> GEMM operand in the active precision."""
     t = t.contiguous()
-    return ops.cast_bf16(t) if get_precision() == "bf16" else t
+    if get_precision() == "32":
+        return t
+    ops.sync_operand_format()                   # (fp16 / bf16 operands as the active precision says)
+    return ops.cast_bf16(t)
 
 
 def _feature_major(W: Tensor) -> Tensor:

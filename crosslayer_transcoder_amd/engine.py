@@ -25,11 +25,11 @@ from . import ops
 from .model.clt import CrosslayerDecoder, Decoder
 from .model.jumprelu import JumpReLU, ReLU
 from .model.topk import BatchTopK, PerLayerBatchTopK, PerLayerTopK
-from .precision import get_precision
+from .precision import LossScaler, get_precision, mixed16
 
 
 def _op(t):
-    return ops.cast_bf16(t.contiguous()) if get_precision() == "bf16" else t.contiguous()
+    return ops.cast_bf16(t.contiguous()) if mixed16() else t.contiguous()
 
 
 def _select(nl, pre):
@@ -124,10 +124,10 @@ def _encoder_operand(enc):
     kept on the module; the fused Adam row pass refreshes it, any other in-place change of W (optimizer,
     load_state_dict) bumps the tensor version and triggers a re-cast."""
     Wt = enc.Wt
-    if get_precision() != "bf16":
+    if not mixed16():
         return Wt
     sh = getattr(enc, "_bf16_shadow", None)
-    ver = (enc.W._version, getattr(enc.W, "_clt_version", 0), Wt.data_ptr())
+    ver = (enc.W._version, getattr(enc.W, "_clt_version", 0), Wt.data_ptr(), ops.op16())
     if sh is None or enc._shadow_version != ver:
         sh = ops.cast_bf16(Wt)
         enc._bf16_shadow, enc._shadow_version = sh, ver
@@ -160,7 +160,7 @@ class _Decoder:
         self.clt = isinstance(dec, CrosslayerDecoder) if clt is None else clt
         self.L = dec.n_layers
         self.W32 = dec.weights()
-        self.bf16 = get_precision() == "bf16"
+        self.bf16 = mixed16()            # (16-bit operands, either format)
         self._Wop = self._WT = self._sq = None
 
     def _prep(self):
@@ -283,7 +283,7 @@ class _Decoder:
     def shadows(self):
         """bf16 copies of the decoder matrices, cast once and then refreshed by the fused Adam row pass; any other
         in-place change of a weight (optimizer.step, load_state_dict) changes its version key and forces a re-cast."""
-        ver = [(w._version, getattr(w, "_clt_version", 0), w.data_ptr()) for w in self.W32]
+        ver = [(w._version, getattr(w, "_clt_version", 0), w.data_ptr(), ops.op16()) for w in self.W32]
         cached = getattr(self.dec, "_bf16_shadows", None)
         if cached is None or cached[0] != ver:
             cached = (ver, [ops.cast_bf16(w.contiguous()) for w in self.W32])
@@ -415,7 +415,21 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     resid, mlp_out = batch[:, 0], batch[:, 1]
     Bn, L, d = resid.shape
     F = enc.d_features
-    bf16 = get_precision() == "bf16"
+    bf16 = mixed16()                            # 16-bit GEMM operands (bf16, or fp16 with loss scaling), fp32 accumulation
+    fp16 = get_precision() == "fp16"
+    if fp16:
+        # `precision: "16-mixed"`: gradients are formed multiplied by the loss scale (the loss kernels' coefficients carry it)
+        # so that they survive the fp16 operand casts, and are unscaled inside the Adam kernels; an overflowing conversion
+        # raises the device flag and every Adam kernel of the step then leaves its parameters untouched.  The caller
+        # (fused_train_step) reads the flag once at the end of the step and moves the scale (precision.LossScaler)
+        scaler = getattr(mod, "loss_scaler", None)
+        if scaler is None:
+            scaler = mod.loss_scaler = LossScaler()
+        flag = ops.inf_flag(batch.device)
+        flag.zero_()
+        ops.set_loss_scaling(True, scaler.scale, flag)
+    else:
+        ops.set_loss_scaling(False)
     kind = mod._loss_kind
     topk_family = isinstance(nl, (PerLayerTopK, BatchTopK, PerLayerBatchTopK))
     # thresholding sparsifiers take the list regime when few entries are active: JumpReLU / ReLU under the JumpReLU module's
@@ -462,7 +476,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                  and (L * F) % 4 == 0)
     # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their
     # GEMMs as bf16 — the K = d_acts GEMMs are bound by their epilogue stores, and the consumers read half the bytes
-    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None
+    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None and not fp16
                  and not (sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0)))
     if S is None:
         pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), enc.b) if act16 else None
@@ -501,7 +515,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     want_ys = kind == "topk"
 
     lists_only = sparse and kind != "jumprelu"           # every gradient comes from the lists (TopK family; ReLU + base loss)
-    pipelined = bool(PIPELINE_EXCHANGE and shard is not None and lists_only and kind == "base" and D.clt)
+    # (not under fp16 loss scaling: a later group's gradient slab could overflow after an earlier group's weights were updated)
+    pipelined = bool(PIPELINE_EXCHANGE and shard is not None and lists_only and kind == "base" and D.clt and not fp16)
     waits = None
     if sparse:
         fired = S.fired
@@ -542,7 +557,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         g = ys = None
         loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
         b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
-        g_lm = torch.empty(L, Bn, d, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        g_lm = torch.empty(L, Bn, d, dtype=ops.op16() if bf16 else torch.float32, device=dev)
 
         group_of = {l: gi for gi, (lo, hi) in enumerate(groups) for l in range(lo, hi)}
         done = set()
@@ -571,6 +586,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         terms = {"mse": (loss_sum[0] / N).float()}
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
     out = StepOutput(terms=terms, grads=grads, dead=dead)
+    out["grad_scale"] = ops.GRAD_SCALE           # out["grads"] carry this factor (1.0 outside fp16 mode)
     out.lazy = {}
     if pipelined:
         out.lazy["recons_norm"] = lambda: r_lm.permute(1, 0, 2).contiguous()
@@ -678,7 +694,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         sq = D.sqnorms()
         g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
         loss16 = fused_ops is not None or (S is not None and fuse_jump)
-        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
+        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS and not fp16))
         if loss16:
             sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                                   mod.pre_actv_loss / (Bn * L))
@@ -687,6 +703,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                                                         mod.pre_actv_loss / (Bn * L))
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
+            if fp16:                          # d(pre) is per shard: every rank must take the same skip decision
+                flag.copy_(shard.all_reduce_sum(flag.clone()))
         if S is not None:
             # list regime: dW_l[l', i, :] = sum over the tokens where feature (l', i) is active of val * g[tok, l, :], plus the
             # row's dec_norms term — one streaming pass per decoder matrix, Adam applied in it when an optimizer is handed in

@@ -26,7 +26,10 @@ def _operand(t: torch.Tensor) -> torch.Tensor:
     """fp32 tensor -> GEMM operand in the active precision."""
     from .. import ops
     t = t.contiguous()
-    return ops.cast_bf16(t) if get_precision() == "bf16" else t
+    if get_precision() == "32":
+        return t
+    ops.sync_operand_format()                   # (fp16 / bf16 operands as the active precision says)
+    return ops.cast_bf16(t)
 
 
 class Encoder(SerializableModule):

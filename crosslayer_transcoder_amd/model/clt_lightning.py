@@ -10,8 +10,9 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .. import engine
+from .. import engine, ops
 from .. import metrics as _metrics
+from ..precision import get_precision
 from ..optim import FusedAdam
 from .clt import CrossLayerTranscoder
 
@@ -206,6 +207,8 @@ class CrossLayerTranscoderModule(_Base):
         names = [n for n in params if n in out["grads"]]
         ps = [params[n] for n in names]
         gs = [out["grads"][n].reshape(params[n].shape) for n in names]
+        if out["grad_scale"] != 1.0:                # fp16 mode: the engine's own loss scale leaves the handed-out gradients
+            gs = [g * (1.0 / out["grad_scale"]) for g in gs]
         return _StepLoss.apply(out["loss"], self.assume_unit_loss_grad, *ps, *gs)
 
     def fused_train_step(self, batch, batch_idx, optimizer: "FusedAdam", scheduler=None, fuse_adam=True, sparse=None,
@@ -218,7 +221,18 @@ class CrossLayerTranscoderModule(_Base):
         for n, p in params.items():
             g = out["grads"].get(n)
             p.grad = None if g is None else g.reshape(p.shape)
-        (stepper if stepper is not None else optimizer).step()
+        scaler = getattr(self, "loss_scaler", None) if get_precision() == "fp16" else None
+        if scaler is not None:
+            # fp16 loss scaling is the library's own (the kernels unscale and skip): the raw optimizer steps, not a wrapper that
+            # would route through an outer GradScaler; one host read of the overflow flag closes the step
+            optimizer.step()
+            skipped = bool(ops.inf_flag(batch.device).item())
+            optimizer.commit(skipped)
+            scaler.update(skipped)
+            self.log("training/loss_scale", scaler.scale)
+        else:
+            (stepper if stepper is not None else optimizer).step()
+            optimizer.commit()
         if scheduler is not None:
             scheduler.step()
         if not HAVE_LIGHTNING:

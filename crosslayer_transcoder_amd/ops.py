@@ -11,8 +11,47 @@ from typing import List, Optional, Tuple
 import torch
 
 from ._lib import CltError, call, lib
+from .precision import operand_dtype as op16
 
 _ws = {}
+_DT16 = (torch.bfloat16, torch.float16)
+
+# ---- 16-bit operand format + loss scaling: process-wide library state (clt_set_loss_scaling) -------------------------------
+#: gradients are formed multiplied by this factor (the loss kernels' coefficients carry it) and unscaled inside the Adam
+#: kernels; 1.0 outside fp16 mode.  Set through set_loss_scaling only.
+GRAD_SCALE = 1.0
+_lib_state = (False, 1.0, 0)
+_flags = {}
+
+
+def inf_flag(device) -> torch.Tensor:
+    """The device int32 that fp32 -> fp16 conversions raise on overflow (one per device, owned here)."""
+    key = torch.device(device).index or 0
+    if key not in _flags:
+        _flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _flags[key]
+
+
+def set_loss_scaling(fp16: bool, scale: float = 1.0, flag: Optional[torch.Tensor] = None):
+    """Bring the library state in line with (operand format, loss scale, overflow flag); a C call (which synchronises the
+    device) only when something changed."""
+    global _lib_state, GRAD_SCALE
+    if fp16 and flag is None:
+        flag = inf_flag(torch.cuda.current_device())
+    want = (bool(fp16), float(scale), flag.data_ptr() if flag is not None else 0)
+    if want != _lib_state:
+        call("clt_set_loss_scaling", int(want[0]), want[1], want[2] or None)
+        _lib_state = want
+    GRAD_SCALE = want[1]
+
+
+def sync_operand_format():
+    """Called by the host paths that launch 16-bit kernels outside the fused step (module forward, inference): operand format
+    from the active precision, no loss scaling of the library's own (an outer GradScaler scales and unscales)."""
+    from .precision import get_precision
+    fp16 = get_precision() == "fp16"
+    if fp16 != _lib_state[0] or _lib_state[1] != 1.0:
+        set_loss_scaling(fp16, 1.0)
 
 #: kernel timing hook (bench.py's roofline pass, run AFTER its timed loop): when a dict, selected launches are bracketed
 #: by HIP events recorded on the launch stream (= torch's current stream) and appended as name -> [(start, end,
@@ -91,7 +130,7 @@ def standardize(x, mean, std, want_f32=True, want_bf16=False):
     _chk(x, contiguous=False); _chk(mean); _chk(std)
     rows, n, rs = _rows_view(x)
     o32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
-    o16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    o16 = torch.empty(x.shape, dtype=op16(), device=x.device) if want_bf16 else None
     call("clt_standardize_f32", x.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n,
          o32.data_ptr() if want_f32 else None, o16.data_ptr() if want_bf16 else None, _stream())
     return o32, o16
@@ -115,7 +154,7 @@ def _gemm(fn, A, aoff, B, boff, Cm, coff, M, N, K, lda, ldb, ldc, tA, tB, batch=
 
 
 def _fn_for(t):
-    return "clt_gemm_bf16" if t.dtype == torch.bfloat16 else "clt_gemm_f32"
+    return "clt_gemm_bf16" if t.dtype in _DT16 else "clt_gemm_f32"
 
 
 def encoder_fwd(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
@@ -216,12 +255,12 @@ def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor], out_bf16: bo
     None when the shape does not qualify."""
     Bn, L, d = g.shape
     F = Ws[0].shape[1]
-    _chk(g, torch.bfloat16)
+    _chk(g, op16())
     if d % 64 or F % 4 or Bn * F < 256 * 256 or (out_bf16 and F % 8):
         return None
     ptrs = []
     for lp in range(L):
-        ptrs += [_chk(Ws[l], torch.bfloat16).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
+        ptrs += [_chk(Ws[l], op16()).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
     table = torch.tensor(ptrs, dtype=torch.int64).to(g.device)
     df = torch.empty(Bn, L, F, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
     off = 0
@@ -296,7 +335,7 @@ def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
     Bn, L, F = fo.shape
     d = WT.shape[1]
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
-    _gemm("clt_gemm_bf16", _chk(fo, torch.bfloat16), 0, _chk(WT, torch.bfloat16), 0, r, 0, Bn, d, F, L * F, F, L * d, False, True,
+    _gemm("clt_gemm_bf16", _chk(fo, op16()), 0, _chk(WT, op16()), 0, r, 0, Bn, d, F, L * F, F, L * d, False, True,
           batch=L, sA=F, sB=d * F, sC=d, bias=b, sBias=d)
     return r
 
@@ -324,12 +363,12 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
             slabs = torch.empty(P, Bn, d, dtype=torch.float32, device=fo.device)
             rec, p = [], 0
             for l in range(l0, l1):
-                wt = _chk(WTs[l], torch.bfloat16).data_ptr()
+                wt = _chk(WTs[l], op16()).data_ptr()
                 for lp in range(l + 1):
                     rec += [lp * F, wt + 2 * lp * d * F, slabs.data_ptr() + p * slab_b]
                     p += 1
             table = torch.tensor(rec, dtype=torch.int64).to(fo.device)
-            rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, torch.bfloat16).data_ptr(),
+            rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, op16()).data_ptr(),
                             table.data_ptr(), P, Bn, d, F, L * F, F, d, _stream())
             if rc == 1 and l0 == 0:
                 ok = False
@@ -346,7 +385,7 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
             return r
     slabs = torch.empty(L, Bn, d, dtype=torch.float32, device=fo.device)
     for l in range(L):
-        _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], torch.bfloat16), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,
+        _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], op16()), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,
               sA=F, sB=d * F, sC=Bn * d)
         call("clt_sum_slabs_f32", slabs.data_ptr(), l + 1, Bn * d, Bn, d, L * d, (b.data_ptr() + 4 * l * d) if b is not None else None,
              r.data_ptr() + 4 * l * d, _stream())
@@ -357,7 +396,7 @@ def wgrad_t(aT: torch.Tensor, bT: torch.Tensor, out: torch.Tensor, batch: int, s
     """out[i] [M, N] (+)= aT[i] [M, K] @ bT[i] [N, K]^T with K = tokens; aT/bT are the token-minor (transposed) bf16
     operands, e.g. features^T [L, F, B] and g^T [L, d, B]."""
     M, N, K = out.shape[-2], out.shape[-1], aT.shape[-1]
-    _gemm("clt_gemm_bf16", _chk(aT, torch.bfloat16), 0, _chk(bT, torch.bfloat16), 0, out, 0, M, N, K, K, K, N, False, True,
+    _gemm("clt_gemm_bf16", _chk(aT, op16()), 0, _chk(bT, op16()), 0, out, 0, M, N, K, K, K, N, False, True,
           batch=batch, sA=sA, sB=sB, sC=M * N, accumulate=accumulate)
     return out
 
@@ -368,7 +407,7 @@ def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Ten
     False when the shape does not qualify (the caller then runs the per-target-layer launches)."""
     L, F, Bn = fT.shape
     d = gT.shape[1]
-    _chk(fT, torch.bfloat16); _chk(gT, torch.bfloat16)
+    _chk(fT, op16()); _chk(gT, op16())
     if Bn % 8 or d % 4 or F * d < 256 * 256:
         return False
     rec = []
@@ -389,7 +428,7 @@ def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Ten
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     _chk(x)
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(x.shape, dtype=op16(), device=x.device)
     call("clt_cast_bf16", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
     return out
 
@@ -398,7 +437,7 @@ def cast_transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     """[batch, rows, cols] fp32 -> [batch, cols, rows] bf16."""
     _chk(x)
     nb, rows, cols = x.shape
-    out = torch.empty(nb, cols, rows, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(nb, cols, rows, dtype=op16(), device=x.device)
     call("clt_cast_transpose_bf16", x.data_ptr(), cols, out.data_ptr(), rows, rows, cols, nb, rows * cols, rows * cols,
          _stream())
     return out
@@ -411,8 +450,8 @@ def weight_prep_bf16(w: torch.Tensor, sq: Optional[torch.Tensor] = None, accumul
     nb, rows, n = w.shape
     if rows % 8 or n % 4:
         return None
-    op = torch.empty(nb, rows, n, dtype=torch.bfloat16, device=w.device)
-    opT = torch.empty(nb, n, rows, dtype=torch.bfloat16, device=w.device)
+    op = torch.empty(nb, rows, n, dtype=op16(), device=w.device)
+    opT = torch.empty(nb, n, rows, dtype=op16(), device=w.device)
     call("clt_weight_prep_bf16", w.data_ptr(), nb, rows, n, op.data_ptr(), opT.data_ptr(),
          _chk(sq).data_ptr() if sq is not None else None, int(accumulate), _stream())
     return op, opT
@@ -518,7 +557,7 @@ def mse(r, y, mean, std, want_grad=True, want_ys=False, count: Optional[int] = N
     loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
     nb = lib.clt_reduce_workspace_bytes(rows * n)
     ws = workspace(nb, r.device)
-    call("clt_mse_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (count or rows * n),
+    call("clt_mse_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, GRAD_SCALE * 2.0 / (count or rows * n),
          g.data_ptr() if want_grad else None, ys.data_ptr() if want_ys else None, loss_sum.data_ptr(), ws.data_ptr(),
          ws.numel(), _stream())
     return loss_sum, g, ys
@@ -533,13 +572,13 @@ def mse_bf16_colsum(r, y, mean, std, count: Optional[int] = None, g16=None, cols
     if n % 4 or rs % 4 or y.data_ptr() % 16 or r.data_ptr() % 16 or mean.data_ptr() % 16 or std.data_ptr() % 16:
         return None
     if g16 is None:
-        g16 = torch.empty(r.shape, dtype=torch.bfloat16, device=r.device)
+        g16 = torch.empty(r.shape, dtype=op16(), device=r.device)
     if colsum is None:
         colsum = torch.empty(mean.shape, dtype=torch.float32, device=r.device)
-    _chk(g16, torch.bfloat16); _chk(colsum)
+    _chk(g16, op16()); _chk(colsum)
     loss_sum = torch.empty(1, dtype=torch.float64, device=r.device)
     ws = workspace(lib.clt_mse_bf16_colsum_workspace_bytes(rows, n), r.device)
-    call("clt_mse_bf16_colsum_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, 2.0 / (count or rows * n),
+    call("clt_mse_bf16_colsum_f32", r.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), rows, n, GRAD_SCALE * 2.0 / (count or rows * n),
          g16.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return loss_sum, g16, colsum
 
@@ -548,7 +587,7 @@ def mse_bf16_colsum_layers(r_lm, y, mean, std, count: int, g16_lm, colsum, loss_
     """mse_bf16_colsum over a group of layers of a layer-major reconstruction: r_lm / g16_lm [nl, B, d] (contiguous slices of
     the [L, B, d] tensors), y = batch[:, 1, lo:lo + nl] ([B, nl, d] view), mean / std / colsum [nl, d], loss_sum fp64 [1]
     (all preallocated views).  False when the layout does not qualify (B % 64, d % 4, alignment)."""
-    _chk(r_lm); _chk(g16_lm, torch.bfloat16); _chk(mean); _chk(std); _chk(colsum); _chk(y, contiguous=False)
+    _chk(r_lm); _chk(g16_lm, op16()); _chk(mean); _chk(std); _chk(colsum); _chk(y, contiguous=False)
     nl, Bn, d = r_lm.shape
     rs = y.stride(0)
     if (Bn % 64 or d % 4 or rs % 4 or y.stride(1) != d or y.stride(2) != 1 or any(t.data_ptr() % 16 for t in (r_lm, y, mean, std))
@@ -556,7 +595,7 @@ def mse_bf16_colsum_layers(r_lm, y, mean, std, count: int, g16_lm, colsum, loss_
         return False
     ws = workspace(lib.clt_mse_bf16_colsum_workspace_bytes(nl * Bn, d), r_lm.device)
     call("clt_mse_bf16_colsum_layers_f32", r_lm.data_ptr(), y.data_ptr(), rs, mean.data_ptr(), std.data_ptr(), nl * Bn, d, Bn,
-         2.0 / count, g16_lm.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+         GRAD_SCALE * 2.0 / count, g16_lm.data_ptr(), colsum.data_ptr(), 0, loss_sum.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return True
 
 
@@ -569,7 +608,7 @@ def aux_mse(aux_r, ys, r, g_main, scale: float):
     s = torch.empty(1, dtype=torch.float64, device=r.device)
     nb = lib.clt_reduce_workspace_bytes(n)
     ws = workspace(nb, r.device)
-    call("clt_aux_mse_f32", aux_r.data_ptr(), ys.data_ptr(), r.data_ptr(), n, scale * 2.0 / n, g_aux.data_ptr(),
+    call("clt_aux_mse_f32", aux_r.data_ptr(), ys.data_ptr(), r.data_ptr(), n, GRAD_SCALE * scale * 2.0 / n, g_aux.data_ptr(),
          g_main.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return s, g_aux
 
@@ -607,8 +646,8 @@ def jumprelu_loss_bwd(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_
     nb = lib.clt_jumprelu_loss_workspace_bytes(rows, n)
     ws = workspace(nb, pre.device)
     call("clt_jumprelu_loss_bwd_f32", pre.data_ptr(), theta.data_ptr(), sq.data_ptr(),
-         _chk(dfeat_main).data_ptr() if have else None, float(bandwidth), float(lam_over_B), float(c), int(use_tanh),
-         float(coef_over_BL), dpre.data_ptr() if have else None, dth.data_ptr() if have else None,
+         _chk(dfeat_main).data_ptr() if have else None, float(bandwidth), float(GRAD_SCALE * lam_over_B), float(c), int(use_tanh),
+         float(GRAD_SCALE * coef_over_BL), dpre.data_ptr() if have else None, dth.data_ptr() if have else None,
          dn.data_ptr() if have else None, sums.data_ptr(), rows, n, ws.data_ptr(), ws.numel(), _stream())
     return sums, dpre, dth, dn
 
@@ -622,8 +661,8 @@ def jumprelu_fwd_bf16(x, theta=None):
     if theta is not None:
         _chk(theta)
         assert theta.numel() == L * F
-    feat = torch.empty(Bn, L, F, dtype=torch.bfloat16, device=x.device)
-    featT = torch.empty(L, F, Bn, dtype=torch.bfloat16, device=x.device)
+    feat = torch.empty(Bn, L, F, dtype=op16(), device=x.device)
+    featT = torch.empty(L, F, Bn, dtype=op16(), device=x.device)
     fired = torch.empty(L, F, dtype=torch.uint8, device=x.device)
     call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype == torch.bfloat16), theta.data_ptr() if theta is not None else None, Bn, L * F, feat.data_ptr(),
          featT.data_ptr(), fired.data_ptr(), _stream())
@@ -638,14 +677,14 @@ def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c,
     Bn, L, F = pre.shape
     n = L * F
     sums = torch.empty(3, dtype=torch.float64, device=pre.device)
-    dpreT = torch.empty(L, F, Bn, dtype=torch.bfloat16, device=pre.device)
+    dpreT = torch.empty(L, F, Bn, dtype=op16(), device=pre.device)
     db = torch.empty(L, F, dtype=torch.float32, device=pre.device)
     dth = torch.empty_like(theta)
     dn = torch.empty(n, dtype=torch.float32, device=pre.device)
     ws = workspace(lib.clt_jumprelu_loss_bf16_workspace_bytes(Bn, n), pre.device)
     call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), int(pre.dtype == torch.bfloat16), theta.data_ptr(), sq.data_ptr(),
          dfeat_main.data_ptr(), int(dfeat_main.dtype == torch.bfloat16), float(bandwidth),
-         float(lam_over_B), float(c), int(use_tanh), float(coef_over_BL), dpreT.data_ptr(), db.data_ptr(), dth.data_ptr(),
+         float(GRAD_SCALE * lam_over_B), float(c), int(use_tanh), float(GRAD_SCALE * coef_over_BL), dpreT.data_ptr(), db.data_ptr(), dth.data_ptr(),
          dn.data_ptr(), sums.data_ptr(), Bn, n, ws.data_ptr(), ws.numel(), _stream())
     return sums, dpreT, db, dth, dn
 
@@ -911,7 +950,7 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     from .parallel import run_sharded_selection
     Bn, L, d = xs.shape
     F = Wt.shape[1]
-    _chk(xs, torch.bfloat16); _chk(Wt, torch.bfloat16)
+    _chk(xs, op16()); _chk(Wt, op16())
     world, rank, f_off, Fg = (shard.world, shard.rank, shard.f_off, shard.F_global) if shard is not None else (1, 0, 0, F)
     kglob = max(1, k * Bn * L)
     if cap is None:
@@ -1067,7 +1106,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
     if ex is not None:
         _chk(ex); _chk(exmap, torch.int32)
         assert ex.shape[-1] == W.shape[-1]
-    src_bf16 = src.dtype == torch.bfloat16
+    src_bf16 = src.dtype in _DT16
     _chk(src, src.dtype)
     d = W.shape[-1]
     rows = W.numel() // d
@@ -1079,7 +1118,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
         # is slab + tok * d (the moved base itself is never dereferenced)
         assert src_layer >= 0 and second is None and src.shape == (s.B, d)
         src_ptr, src_L = src.data_ptr() - src_layer * d * src.element_size(), 1
-    if x2 is not None and (x2.dtype == torch.bfloat16) != src_bf16:
+    if x2 is not None and (x2.dtype in _DT16) != src_bf16:
         raise TypeError("both gather sources must have the same dtype")
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     _timed_call("row_pass", (rows, d, col0, src_layer, grad_out is None, 2 if src_bf16 else 4, shadow is not None), "clt_sparse_row_pass_f32", W.data_ptr(), ptr(m), ptr(v), ptr(shadow), ptr(grad_out), rows, d, s.F, src_L, col0,

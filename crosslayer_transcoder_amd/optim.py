@@ -21,6 +21,7 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
         self._row_terms = {}
+        self._stepped = []          # parameters whose step count moved since the last commit() (fp16 loss scaling)
 
     def add_row_term(self, p, dnorm, sq):
         """The next step() adds (dnorm[r] / sqrt(sq[r])) * p[r, :] to p's gradient inside the update kernel (the
@@ -49,9 +50,18 @@ class FusedAdam(torch.optim.Optimizer):
         group = self._group_of(p)
         st = self._state(p)
         st["step"] += 1
+        self._stepped.append(p)
         b1, b2 = group["betas"]
         return dict(adam=dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                               adamw=group["adamw"], step=st["step"]), m=st["exp_avg"], v=st["exp_avg_sq"])
+
+    def commit(self, skipped: bool = False):
+        """End of an optimisation step under loss scaling: when the kernels skipped the update (overflow flag raised, see
+        ops.set_loss_scaling) the step counts taken for it are given back, as GradScaler.step leaves them."""
+        if skipped:
+            for p in self._stepped:
+                self.state[p]["step"] -= 1
+        self._stepped = []
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,6 +76,7 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 st = self._state(p)
                 st["step"] += 1
+                self._stepped.append(p)
                 g = _same_layout(p.grad, p)
                 ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
                          group["weight_decay"], group["adamw"], None, self._row_terms.pop(id(p), None))

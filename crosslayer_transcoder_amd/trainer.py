@@ -6,7 +6,6 @@ instantiated from its class_path/init_args nodes (reference package prefix accep
 training_step runs forward + backward + Adam itself; with `fused_step=False` the automatic-optimisation order
 training_step -> backward -> optimizer.step -> scheduler.step is run here."""
 import itertools
-import warnings
 from typing import Iterable, Optional
 
 import torch
@@ -44,17 +43,9 @@ def build_datamodule(cfg: dict):
 
 
 def apply_trainer_precision(cfg: dict):
-    """`trainer.precision`: "32" and "bf16-mixed" map one to one.  "16-mixed" (fp16 autocast + GradScaler, the
-    setting of the reference's production YAMLs, config/default.yaml:13) has no fp16 kernels here: it runs as
-    bf16-mixed — bf16 operands, fp32 accumulate, no loss scaling (bf16 has fp32's exponent range, so the
-    scaler's job does not arise) — and says so once."""
-    prec = str((cfg.get("trainer") or {}).get("precision", "32"))
-    if prec in ("16-mixed", "16", "fp16"):
-        warnings.warn("trainer.precision '16-mixed' (fp16 + GradScaler) is run as 'bf16-mixed' by crosslayer_transcoder_amd: "
-                      "bf16 MFMA operands, fp32 accumulation, no loss scaling.  Results differ from an fp16 run at the "
-                      "bf16 tolerance (rtol 2e-2).", UserWarning, stacklevel=2)
-        prec = "bf16-mixed"
-    set_precision(prec)
+    """`trainer.precision`: "32", "bf16-mixed" and "16-mixed" (fp16 operands + dynamic loss scaling, the setting of the
+    reference's production YAMLs, config/default.yaml:13) map one to one onto precision.set_precision."""
+    set_precision(str((cfg.get("trainer") or {}).get("precision", "32")))
 
 
 def fit(module, batches: Iterable[torch.Tensor], max_steps: int, device="cuda:0", fused: Optional[bool] = None,

@@ -214,6 +214,18 @@ int clt_column_any_positive_f32(const float* feat, int rows, int n, uint8_t* fir
 int clt_dead_update(const uint8_t* fired, int n, long tokens, int64_t* last_active, long tokens_till_dead,
                     uint8_t* dead, int32_t* dead_count, void* stream);
 
+/* 16-bit operand format and loss scaling — process-wide library state, like a BLAS math mode (reference: Lightning
+ * `precision: "16-mixed"`, config/default.yaml:13 = torch.autocast(float16) + torch.amp.GradScaler around
+ * clt_lightning.py:290-312).  fp16_operands = 1: every kernel that writes or reads a 16-bit GEMM operand (casts, shadows,
+ * gathered sources, the MFMA GEMMs — all entry points named *_bf16 included) uses IEEE fp16 instead of bf16.
+ * loss_scale: the factor the caller multiplied the loss gradient by; clt_adam_f32 and the Adam inside
+ * clt_sparse_row_pass_f32 multiply gradients by 1 / loss_scale.  found_inf (device int32, required with fp16 operands):
+ * set to 1 by any fp32 -> fp16 conversion whose result is inf or NaN; while it is set the Adam kernels leave parameters,
+ * moments and shadows untouched (GradScaler's skipped step).  The caller clears it before a step and reads it after.
+ * Synchronises the device; applies to the device current at the call.  Default: (0, 1.0, NULL). */
+int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf);
+int clt_operand_format(void);     /* 0 bf16, 1 fp16 */
+
 /* ---------------------------------------------------------------------------------------------
  * K13  fused Adam / AdamW — clt_lightning.py:339-352 (torch.optim semantics, eps outside sqrt)
  * step counts from 1; hyper-parameters are doubles (torch derives 1-beta and the bias corrections in

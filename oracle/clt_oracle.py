@@ -32,25 +32,36 @@ Tensor = torch.Tensor
 # Optional emulation of the build's bf16 mode (bf16 GEMM operands, fp32 accumulate and fp32 results): every
 # dense-contraction operand passes through _q().  None = exact fp32/fp64 restatement of the reference.
 _OPERAND_DTYPE = None
+_GRAD_SCALE = 1.0
 
 
 class operand_rounding:
-    """with operand_rounding(torch.bfloat16): ...  — round GEMM operands as the bf16 MFMA path does."""
+    """with operand_rounding(torch.bfloat16): ...  — round GEMM operands as the 16-bit MFMA path does.
+    grad_scale (fp16 mode, `precision: "16-mixed"`): gradient operands are rounded while multiplied by the loss scale, as
+    they are under torch.amp.GradScaler (scale the loss, backward in fp16, unscale the fp32 gradients); an overflow shows
+    as inf / NaN in the gradients, which the caller treats as a skipped step."""
 
-    def __init__(self, dtype):
-        self.dtype = dtype
+    def __init__(self, dtype, grad_scale: float = 1.0):
+        self.dtype, self.grad_scale = dtype, float(grad_scale)
 
     def __enter__(self):
-        global _OPERAND_DTYPE
-        self.old, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+        global _OPERAND_DTYPE, _GRAD_SCALE
+        self.old, _OPERAND_DTYPE, _GRAD_SCALE = (_OPERAND_DTYPE, _GRAD_SCALE), self.dtype, self.grad_scale
 
     def __exit__(self, *a):
-        global _OPERAND_DTYPE
-        _OPERAND_DTYPE = self.old
+        global _OPERAND_DTYPE, _GRAD_SCALE
+        _OPERAND_DTYPE, _GRAD_SCALE = self.old
 
 
 def _q(t: Tensor) -> Tensor:
     return t if _OPERAND_DTYPE is None else t.to(_OPERAND_DTYPE).to(t.dtype)
+
+
+def _qg(t: Tensor) -> Tensor:
+    """A gradient as a GEMM operand: rounded while it carries the loss scale."""
+    if _OPERAND_DTYPE is None:
+        return t
+    return (t * _GRAD_SCALE).to(_OPERAND_DTYPE).to(t.dtype) / _GRAD_SCALE
 
 
 # --------------------------------------------------------------------------------------------
@@ -99,7 +110,7 @@ def encoder_fwd_layer(x: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
 def encoder_bwd(xs: Tensor, dpre: Tensor) -> Tuple[Tensor, Tensor]:
     """dW[l] = xs[:,l]^T @ dpre[:,l];  db = sum_b dpre.  (No dx: the batch does not require grad.)"""
     L = xs.shape[1]
-    dW = torch.stack([_q(xs[:, l]).T @ _q(dpre[:, l]) for l in range(L)])
+    dW = torch.stack([_q(xs[:, l]).T @ _qg(dpre[:, l]) for l in range(L)])
     return dW, dpre.sum(dim=0)
 
 
@@ -227,8 +238,8 @@ def crosslayer_decoder_bwd(feat: Tensor, Ws: List[Tensor], g: Tensor) -> Tuple[T
     for l in range(L):
         dW = torch.empty_like(Ws[l])
         for lp in range(l + 1):
-            dfeat[:, lp] += _q(g[:, l]) @ _q(Ws[l][lp]).T
-            dW[lp] = _q(feat[:, lp]).T @ _q(g[:, l])
+            dfeat[:, lp] += _qg(g[:, l]) @ _q(Ws[l][lp]).T
+            dW[lp] = _q(feat[:, lp]).T @ _qg(g[:, l])
         dWs.append(dW)
     return dfeat, dWs, g.sum(dim=0)
 
@@ -255,8 +266,8 @@ def crosslayer_decoder_fwd_layer(feat: Tensor, Ws: List[Tensor], b: Tensor, laye
 
 def plt_decoder_bwd(feat: Tensor, W: Tensor, g: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     L = feat.shape[1]
-    dfeat = torch.stack([_q(g[:, l]) @ _q(W[l]).T for l in range(L)], dim=1)
-    dW = torch.stack([_q(feat[:, l]).T @ _q(g[:, l]) for l in range(L)])
+    dfeat = torch.stack([_qg(g[:, l]) @ _q(W[l]).T for l in range(L)], dim=1)
+    dW = torch.stack([_q(feat[:, l]).T @ _qg(g[:, l]) for l in range(L)])
     return dfeat, dW, g.sum(dim=0)
 
 

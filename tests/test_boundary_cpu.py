@@ -123,11 +123,23 @@ def test_own_debug_config_builds_module_and_datamodule():
     assert conf["optimizer"].param_groups[0]["lr"] == 1e-3 and conf["lr_scheduler"]["name"] == "step_decay"
     dm = trainer.build_datamodule(cfg)
     assert dm.batch_size == 16 and dm.shuffle and dm.tensor_file.endswith("debug_actvs.pt")
-    with pytest.warns(UserWarning, match="16-mixed"):
-        trainer.apply_trainer_precision({"trainer": {"precision": "16-mixed"}})
+    # trainer.precision of the reference's production YAMLs: fp16 operands + dynamic loss scaling (GradScaler's rule)
+    trainer.apply_trainer_precision({"trainer": {"precision": "16-mixed"}})
+    import torch
     from crosslayer_transcoder_amd import get_precision, set_precision
-    assert get_precision() == "bf16"
+    from crosslayer_transcoder_amd.precision import LossScaler, mixed16, operand_dtype
+    assert get_precision() == "fp16" and mixed16() and operand_dtype() == torch.float16
+    set_precision("bf16-mixed")
+    assert operand_dtype() == torch.bfloat16 and mixed16()
     set_precision("32")
+    assert not mixed16()
+    sc = LossScaler(growth_interval=3)
+    assert sc.scale == 65536.0
+    sc.update(True)
+    assert sc.scale == 32768.0 and sc.skipped_steps == 1
+    for _ in range(3):
+        sc.update(False)
+    assert sc.scale == 65536.0 and sc.growth_tracker == 0
 
 
 def test_forward_ops_are_registered_with_the_dispatcher():
