@@ -204,6 +204,8 @@ def parse_args():
     ap.add_argument("--rehearsal", action="store_true",
                     help="--gpus N on a machine with fewer than N GPUs: ranks share the GPUs and exchange over gloo with host "
                          "staging.  A schedule rehearsal, NOT a scaling measurement (the line says so)")
+    ap.add_argument("--distinct-batches", type=int, default=N_BATCHES,
+                    help="resident synthetic batches cycled through the steps (fewer only where HBM is short: config 5 on one GPU)")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU-oracle time after which no further step starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,7 +273,7 @@ def main():
     mod = build(args, device, world)
     opt, sched = mod.attach_optimizers()
     A = synth_target_map(args.layers, args.d_acts, device)
-    batches = [synth_batch(args.batch, args.layers, args.d_acts, device, seed=i, A=A) for i in range(N_BATCHES)]
+    batches = [synth_batch(args.batch, args.layers, args.d_acts, device, seed=i, A=A) for i in range(args.distinct_batches)]
 
     def barrier():
         if dist is not None:
@@ -287,7 +289,7 @@ def main():
     step = 0
 
     def nxt():
-        return next(feed) if feed is not None else batches[step % N_BATCHES]
+        return next(feed) if feed is not None else batches[step % args.distinct_batches]
 
     sparse = {"auto": None, "on": True, "off": False}[args.sparse]
     if sparse is not None:
@@ -341,7 +343,7 @@ def main():
                                + (f"(k={args.k})" if args.nonlinearity in ("batchtopk", "topk") else "")
                                + f" L={L} d={d} F={F}/layer B={args.batch}"
                                + (" +aux(k=512)" if args.aux else ""),
-                   "parallelism": par, "ingest": args.ingest, "api": args.api, "distinct_batches": N_BATCHES,
+                   "parallelism": par, "ingest": args.ingest, "api": args.api, "distinct_batches": args.distinct_batches,
                    "regime": "activation lists" if mod.last_step.get("lists") is not None else "dense GEMM",
                    "fused_select_steps": stats.get("fused_select_steps", 0), "select_fallbacks": stats.get("select_fallbacks", 0),
                    "loss": float(mod.last_step["loss"])},
