@@ -204,6 +204,8 @@ def parse_args():
     ap.add_argument("--rehearsal", action="store_true",
                     help="--gpus N on a machine with fewer than N GPUs: ranks share the GPUs and exchange over gloo with host "
                          "staging.  A schedule rehearsal, NOT a scaling measurement (the line says so)")
+    ap.add_argument("--select-margin", type=float, default=None,
+                    help="fused encoder+select: candidate bound = margin x last step's k-th value (default: engine.SELECT_MARGIN)")
     ap.add_argument("--distinct-batches", type=int, default=N_BATCHES,
                     help="resident synthetic batches cycled through the steps (fewer only where HBM is short: config 5 on one GPU)")
     ap.add_argument("--cpu-batch", type=int, default=256)
@@ -270,6 +272,9 @@ def main():
     import crosslayer_transcoder_amd as cta
     from crosslayer_transcoder_amd import engine, ops
     cta.set_precision(args.precision)
+    if args.select_margin is not None:
+        import crosslayer_transcoder_amd.engine as _engine
+        _engine.SELECT_MARGIN = args.select_margin
     mod = build(args, device, world)
     opt, sched = mod.attach_optimizers()
     A = synth_target_map(args.layers, args.d_acts, device)
@@ -346,6 +351,8 @@ def main():
                    "parallelism": par, "ingest": args.ingest, "api": args.api, "distinct_batches": args.distinct_batches,
                    "regime": "activation lists" if mod.last_step.get("lists") is not None else "dense GEMM",
                    "fused_select_steps": stats.get("fused_select_steps", 0), "select_fallbacks": stats.get("select_fallbacks", 0),
+                   "select_drift": (lambda t: None if t is None else [round(float(v), 5) for v in t[: t.numel() // 2].tolist()])(
+                       getattr(mod.model.nonlinearity, "_kth_drift", None)),
                    "loss": float(mod.last_step["loss"])},
     }
     if rank == 0:

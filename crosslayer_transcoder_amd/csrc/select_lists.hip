@@ -82,11 +82,24 @@ __global__ __launch_bounds__(TPB) void sample_kernel(uint32_t ns, uint32_t rank,
 }
 
 // ext mode, stage 0: lower bound from the previous step's exact k-th value (positive, else the attempt is void)
-__global__ void ext_lb_kernel(const uint32_t* __restrict__ prev_T, float margin, int S, uint32_t Kseg, SegState* __restrict__ state,
-                              SelCtl* __restrict__ ctl, Head* __restrict__ head) {
+// drift (optional, [2 S] floats kept by the caller from step to step): [s] = peak-hold (decay 0.95 a step) of the relative
+// change |T_t / T_{t-1} - 1| of the k-th value, [S + s] = the k-th value before prev_T.  With it the bound tightens from
+// `margin` (the floor) to 1 - 2.5 drift - 0.005, at most 0.98: the k-th of 786 k values out of 1.6 G moves by 1-2 % a step
+// early in training (measured on the synthetic headline: bound 0.96, -0.03 ms) and less as the weights settle; every candidate
+// less is epilogue work saved.  A caller raises drift[s] (0.1: the floor for
+// ~30 steps) after a void attempt.
+__global__ void ext_lb_kernel(const uint32_t* __restrict__ prev_T, float margin, float* __restrict__ drift, int S, uint32_t Kseg,
+                              SegState* __restrict__ state, SelCtl* __restrict__ ctl, Head* __restrict__ head) {
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         const float T = key_f32(prev_T[s]);
         if (!(T > 0.0f) || !(T < INFINITY)) head->gate = 1;
+        if (drift) {
+            const float T2 = drift[S + s];
+            float dr = drift[s] * 0.95f;
+            dr = (T2 > 0.0f && T > 0.0f) ? fmaxf(dr, fabsf(T / T2 - 1.0f)) : fmaxf(dr, 0.025f);      // (no history: the floor)
+            drift[s] = dr; drift[S + s] = T;
+            margin = fminf(fmaxf(1.0f - 2.5f * dr - 0.005f, margin), 0.98f);
+        }
         ctl[s].lb = f32_key(T * margin);
         SegState st; st.prefix = 0; st.mask = 0; st.krem = Kseg; st.eq_total = 0; state[s] = st;
     }
@@ -440,7 +453,7 @@ struct SelArgs {
     uint32_t* row_start; int32_t* ent_col; float* ent_val; uint32_t* col_start; int32_t* csc_tok; float* csc_val;
     int32_t* csc_ent; uint8_t* fired; uint32_t* total; int32_t* overflow; float* dense_scratch; int32_t* used_fallback;
     void* ws; size_t wsb; hipStream_t st; Shard sd; int exhaustive;
-    const uint32_t* prev_T; float margin;        // ext mode (exhaustive & 2): lower bound = margin * last step's k-th value
+    const uint32_t* prev_T; float margin; float* drift = nullptr;        // ext mode (exhaustive & 2): lower bound = margin * last step's k-th value
 };
 
 // Stages (batch modes):  0 clear + sample -> lb            [sharded: MIN of lb over ranks]
@@ -506,7 +519,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             if (hipMemsetAsync(a.ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
             if (mode == 0) continue;
             if (a.exhaustive & 2) {
-                hipLaunchKernelGGL(ext_lb_kernel, dim3(1), dim3(64), 0, st, a.prev_T, a.margin, p.S, p.Kseg, state, ctl, head);
+                hipLaunchKernelGGL(ext_lb_kernel, dim3(1), dim3(64), 0, st, a.prev_T, a.margin, a.drift, p.S, p.Kseg, state, ctl, head);
                 continue;
             }
             if (p.rank < p.ns)
@@ -672,7 +685,7 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
 }
 
 int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, const uint32_t* prev_T,
-                             float margin, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
+                             float margin, float* drift, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                              float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                              int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
@@ -680,7 +693,7 @@ int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, in
     if (f_off < 0 || f_off + F > F_global || !(margin > 0.0f && margin <= 1.0f)) return CLT_ERR_SHAPE;
     SelArgs a{nullptr, nullptr, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
               csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),
-              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, 2 | 4, prev_T, margin};
+              Shard{world, rank, (uint32_t)f_off, (uint32_t)F_global}, 2 | 4, prev_T, margin, drift};
     return run_stages(a, stage_lo, stage_hi);
 }
 }  // extern "C"

@@ -92,6 +92,9 @@ STATS = {"fused_select_steps": 0, "select_fallbacks": 0}
 FUSE_ENCODER_SELECT = True
 #: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
 SELECT_MARGIN = 0.9
+#: tighten that bound from the floor SELECT_MARGIN towards 0.98 as far as the observed step-to-step change of the k-th value
+#: allows (device-side peak-hold of |T_t / T_{t-1} - 1|, clt_select_lists_ext_f32's drift state): fewer candidates in the epilogue
+ADAPTIVE_SELECT_MARGIN = True
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
@@ -465,13 +468,19 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
             and getattr(nl, "_kth", None) is not None and d % 8 == 0 and F % 4 == 0):
         mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
+        nseg = L if isinstance(nl, PerLayerBatchTopK) else 1
+        drift = getattr(nl, "_kth_drift", None)
+        if ADAPTIVE_SELECT_MARGIN and (drift is None or drift.numel() != 2 * nseg or drift.device != dev):
+            drift = nl._kth_drift = ops.new_select_drift(nseg, dev)
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
-                                          nl.e, shard)
+                                          nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None)
         STATS["fused_select_steps"] += 1
         if S is not None:
             nl._kth = kth
         else:
             STATS["select_fallbacks"] += 1
+            if drift is not None:
+                drift[:nseg] = 0.1               # the bound did not hold: back to the floor for ~30 steps, then tighten again
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
     # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their

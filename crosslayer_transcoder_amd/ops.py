@@ -942,11 +942,14 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
 
 
 def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor], k: int, mode: int, prev_T: torch.Tensor,
-                         margin: float, threshold: Optional[torch.Tensor], e: float, shard=None, cap: Optional[int] = None):
+                         margin: float, threshold: Optional[torch.Tensor], e: float, shard=None, cap: Optional[int] = None,
+                         drift: Optional[torch.Tensor] = None):
     """Encoder forward fused with the BatchTopK / PerLayerBatchTopK selection: the bf16 NT GEMM's epilogue appends the
     candidates (>= margin * last step's k-th value, `prev_T` int32 keys [S]) and the pre-activation tensor is never
     written.  Returns (lists, T) — T = int32 keys [S] of this step's exact k-th values — or (None, None) when the
-    attempt was void (one host read) and the caller must run the ordinary GEMM + selection."""
+    attempt was void (one host read) and the caller must run the ordinary GEMM + selection.
+    drift: fp32 [2 S] kept by the caller across steps (new_select_drift): the bound then tightens from `margin` towards
+    0.98 as far as the observed step-to-step change of the k-th value allows (clt_select_lists_ext_f32)."""
     from .parallel import run_sharded_selection
     Bn, L, d = xs.shape
     F = Wt.shape[1]
@@ -967,8 +970,8 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     base = ws.data_ptr()
 
     def stages(lo, hi):
-        call("clt_select_lists_ext_f32", lo, hi, world, rank, f_off, Fg, prev_T.data_ptr(), float(margin), Bn, L, F, k, mode,
-             threshold.data_ptr() if threshold is not None else None, float(e or 0.0), s.cap, s.row_start.data_ptr(),
+        call("clt_select_lists_ext_f32", lo, hi, world, rank, f_off, Fg, prev_T.data_ptr(), float(margin),
+             _chk(drift).data_ptr() if drift is not None else None, Bn, L, F, k, mode, threshold.data_ptr() if threshold is not None else None, float(e or 0.0), s.cap, s.row_start.data_ptr(),
              s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(),
              s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), fb.data_ptr(), base,
              ws.numel(), _stream())
@@ -997,6 +1000,11 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     s.used_fallback = fb
     s.kth = T
     return s, T
+
+
+def new_select_drift(S: int, device) -> torch.Tensor:
+    """Initial state of the adaptive candidate bound: no history (the bound starts at its floor and tightens over ~30 steps)."""
+    return torch.zeros(2 * S, device=device)
 
 
 class FlagProbe:

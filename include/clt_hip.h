@@ -332,9 +332,11 @@ int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int
  * exchange queries with flags = 2); stage 5 merges the outcome over shards and PUBLISHES used_fallback[0], stage 6 emits
  * the selection and builds the lists — so the host can fetch the flag (side stream) while stage 6 runs.
  * used_fallback[0] != 0: the attempt is void (bound too high, overflow, too many ties, previous value not positive):
- * nothing is emitted, the caller runs the ordinary path. */
+ * nothing is emitted, the caller runs the ordinary path.
+ * drift (optional, [2 S] floats the caller keeps from step to step, initially zeros: stage 0 tracks the relative
+ * change of the k-th value in it and tightens the bound from `margin` (the floor) to 1 - 2.5 drift - 0.005, at most 0.98. */
 int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, int f_off, int F_global, const uint32_t* prev_T,
-                             float margin, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
+                             float margin, float* drift, int B, int L, int F, int k, int mode, float* threshold, float ema_e, uint32_t cap,
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                              float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                              int32_t* used_fallback, void* workspace, size_t ws_bytes, void* stream);

@@ -159,7 +159,7 @@ def gpu_bf16_fused_sharded(rank, world):
               "decoder.b": torch.zeros(L, d)}
     for l in range(L):
         params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
-    for kind in ("batchtopk", "perlayerbatchtopk"):
+    for kind, prec in (("batchtopk", "bf16-mixed"), ("perlayerbatchtopk", "bf16-mixed"), ("batchtopk", "16-mixed")):
         case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": kind, "k": 8, "e": 0.1},
                         "loss": {"kind": "base"}}, "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
                 "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
@@ -169,7 +169,7 @@ def gpu_bf16_fused_sharded(rank, world):
         shard_module(part, shard)
         of, op = full.configure_optimizers(), part.configure_optimizers()
         fused = 0
-        with precision("bf16-mixed"):
+        with precision(prec):                     # ("16-mixed": fp16 operands, the library's loss scaling on every rank alike)
             for t, b in enumerate(batches):
                 lf = full.fused_train_step(b.cuda(), t, of)
                 lp = part.fused_train_step(b.cuda(), t, op)
@@ -178,6 +178,8 @@ def gpu_bf16_fused_sharded(rank, world):
                 want = shard.slice_features(full.last_step["features"], 2)
                 assert torch.equal(part.last_step["features"] > 0, want > 0), f"{kind}: active set differs at step {t}"
         assert fused == 3, "the fused encoder+filter epilogue should run on steps 1..3"
+        if prec == "16-mixed":
+            assert part.loss_scaler.scale == full.loss_scaler.scale == 65536.0 and part.loss_scaler.skipped_steps == 0
         assert_close(part.model.nonlinearity.threshold, full.model.nonlinearity.threshold, 1e-6, 0, "threshold")
         fp = dict(full.model.named_parameters())
         for k, p in part.model.named_parameters():
