@@ -38,6 +38,8 @@ def set_loss_scaling(fp16: bool, scale: float = 1.0, flag: Optional[torch.Tensor
     global _lib_state, GRAD_SCALE
     if fp16 and flag is None:
         flag = inf_flag(torch.cuda.current_device())
+    if flag is not None and flag.device.index != torch.cuda.current_device():
+        raise RuntimeError("loss-scaling state applies to the current device: run the fp16 step with torch.cuda.set_device(module's device)")
     want = (bool(fp16), float(scale), flag.data_ptr() if flag is not None else 0)
     if want != _lib_state:
         call("clt_set_loss_scaling", int(want[0]), want[1], want[2] or None)
