@@ -193,19 +193,49 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
     if (cin) { mu = *reinterpret_cast<const float4*>(mean + col); sd = *reinterpret_cast<const float4*>(stdv + col); }
     float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     double acc = 0.0;
-#pragma unroll 4
-    for (int i = 0; i < MF_R / 4; ++i) {
-        const int row = r0 + w + 4 * i;
-        if (!cin || row >= rows) continue;
-        const float4 rv = *reinterpret_cast<const float4*>(r + (long)row * n + col);
-        const float4 yv = *reinterpret_cast<const float4*>(y + (long)row * yrs + col);
-        const float d0 = rv.x - (yv.x - mu.x) / sd.x, d1 = rv.y - (yv.y - mu.y) / sd.y;
-        const float d2 = rv.z - (yv.z - mu.z) / sd.z, d3 = rv.w - (yv.w - mu.w) / sd.w;
-        const float g0 = gs * d0, g1 = gs * d1, g2 = gs * d2, g3 = gs * d3;
-        cs[0] += g0; cs[1] += g1; cs[2] += g2; cs[3] += g3;
-        acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
-        *reinterpret_cast<uint2*>(g16 + (long)row * n + col) =
-            make_uint2(pack16<F16>(g0, g1), pack16<F16>(g2, g3));
+    // (8 rows = 16 loads of 16 bytes in flight per thread)
+    for (int i0 = 0; i0 < MF_R / 4; i0 += 8) {
+        float4 rv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = r0 + w + 4 * (i0 + u);
+            if (cin && row < rows) {
+                rv[u] = *reinterpret_cast<const float4*>(r + (long)row * n + col);
+                yv[u] = *reinterpret_cast<const float4*>(y + (long)row * yrs + col);
+            }
+        }
+        // (the bf16 rows leave by 16-byte stores where the shape allows: neighbouring lanes trade the halves of two rows — the
+        // even lane stores 8 columns of row u, the odd lane 8 columns of row u + 1; 8-byte stores run at about half the rate)
+        const bool wide = (n & 7) == 0 && (rows & (MF_R - 1)) == 0 && (reinterpret_cast<uintptr_t>(g16) & 15) == 0;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            uint32_t q[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int row = r0 + w + 4 * (i0 + u + e);
+                q[e][0] = q[e][1] = 0;
+                if (!cin || row >= rows) continue;
+                const float4 rr = rv[u + e], yy = yv[u + e];
+                // (IEEE division kept — a multiply by 1 / std would save 6 of 46 us on a 6-layer slab, but the bf16 rows are
+                // defined as the rounding of clt_mse_f32's gradient, bit for bit)
+                const float d0 = rr.x - (yy.x - mu.x) / sd.x, d1 = rr.y - (yy.y - mu.y) / sd.y;
+                const float d2 = rr.z - (yy.z - mu.z) / sd.z, d3 = rr.w - (yy.w - mu.w) / sd.w;
+                const float g0 = gs * d0, g1 = gs * d1, g2 = gs * d2, g3 = gs * d3;
+                cs[0] += g0; cs[1] += g1; cs[2] += g2; cs[3] += g3;
+                acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+                q[e][0] = pack16<F16>(g0, g1); q[e][1] = pack16<F16>(g2, g3);
+                if (!wide) *reinterpret_cast<uint2*>(g16 + (long)row * n + col) = make_uint2(q[e][0], q[e][1]);
+            }
+            if (wide) {
+                const bool odd = tx & 1;
+                const uint32_t x0 = __shfl_xor(odd ? q[0][0] : q[1][0], 1, 64), x1 = __shfl_xor(odd ? q[0][1] : q[1][1], 1, 64);
+                const long row = r0 + w + 4 * (i0 + u + (odd ? 1 : 0));
+                if (cin) {
+                    if (odd) *reinterpret_cast<uint4*>(g16 + row * n + col - 4) = make_uint4(x0, x1, q[1][0], q[1][1]);
+                    else *reinterpret_cast<uint4*>(g16 + row * n + col) = make_uint4(q[0][0], q[0][1], x0, x1);
+                }
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) red[w][4 * tx + k] = cs[k];
@@ -216,13 +246,26 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
     if (c < n) part_c[(long)blockIdx.y * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // out[g][c] (+)= sum over the chunks of group g (blockIdx.y; nchunks consecutive chunks each) of part[chunk][c], fixed order
-__global__ void sum_chunks_kernel(const float* __restrict__ part, int nchunks, int n, float* __restrict__ out, int accumulate) {
+// The block after the column blocks (blockIdx.x == gridDim.x - 1, group 0) adds the nb_l loss partials into loss_sum[0]
+// (when part_l is given): one launch finishes both reductions of the pass.
+__global__ void sum_chunks_kernel(const float* __restrict__ part, int nchunks, int n, float* __restrict__ out, int accumulate,
+                                  const double* __restrict__ part_l, int nb_l, double* __restrict__ loss_sum) {
+    if (part_l && blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0 && threadIdx.x < 64) {
+            double s = 0.0;
+            for (int b = threadIdx.x; b < nb_l; b += 64) s += part_l[b];
+            s = wave_sum_d(s);
+            if (threadIdx.x == 0) loss_sum[0] = s;
+        }
+        return;
+    }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     part += (long)blockIdx.y * nchunks * n;
     out += (long)blockIdx.y * n;
     float s = 0.0f;
-    for (int k = 0; k < nchunks; ++k) s += part[(long)k * n + c];
+#pragma unroll 8
+    for (int k = 0; k < nchunks; ++k) s += part[(long)k * n + c];          // (fixed order; the loads of 8 chunks in flight)
     out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -883,10 +926,9 @@ static int mse_bf16_colsum_impl(const float* r, const float* y, long yrs, const 
                        part_c, part_l, layer_rows);
     else hipLaunchKernelGGL((mse_bf16_colsum_kernel<false>), dim3(ctiles, chunks), dim3(256), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g16,
                        part_c, part_l, layer_rows);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)part_l, chunks * ctiles, 1, loss_sum);
     const int groups = layer_rows > 0 ? rows / layer_rows : 1;        // column sums per layer: colsum is [layers][n]
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256, groups), dim3(256), 0, as_stream(st), (const float*)part_c, chunks / groups, n,
-                       colsum, accumulate);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 255) / 256 + 1, groups), dim3(256), 0, as_stream(st), (const float*)part_c, chunks / groups, n,
+                       colsum, accumulate, (const double*)part_l, chunks * ctiles, loss_sum);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_mse_bf16_colsum_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n, float gs,
