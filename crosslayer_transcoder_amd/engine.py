@@ -95,6 +95,8 @@ SELECT_MARGIN = 0.9
 #: tighten that bound from the floor SELECT_MARGIN towards 0.98 as far as the observed step-to-step change of the k-th value
 #: allows (device-side peak-hold of |T_t / T_{t-1} - 1|, clt_select_lists_ext_f32's drift state): fewer candidates in the epilogue
 ADAPTIVE_SELECT_MARGIN = True
+#: queue the decoder's gather forward before the host reads the fused selection's outcome flag
+SPECULATIVE_FORWARD = True
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
@@ -472,8 +474,17 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         drift = getattr(nl, "_kth_drift", None)
         if ADAPTIVE_SELECT_MARGIN and (drift is None or drift.numel() != 2 * nseg or drift.device != dev):
             drift = nl._kth_drift = ops.new_select_drift(nseg, dev)
+        # the decoder's gather forward is queued BEFORE the host reads whether the bound held (it only reads the lists, which
+        # are empty after a void attempt): the launch queue does not run dry behind that read — on an 8-way shard, where
+        # every kernel is 8 times shorter, the GPU otherwise idled ~0.2 ms a step there
+        def _spec_fwd(S_):
+            D_ = _Decoder(dec, shard, shadow=optimizer is not None)
+            lm = bool(PIPELINE_EXCHANGE and shard is not None and D_.clt and not fp16)
+            return D_, lm, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow, layer_major=lm)
+
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
-                                          nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None)
+                                          nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
+                                          speculate=_spec_fwd if SPECULATIVE_FORWARD else None)
         STATS["fused_select_steps"] += 1
         if S is not None:
             nl._kth = kth
@@ -518,7 +529,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     else:
         raise NotImplementedError(f"fused step: unsupported nonlinearity {type(nl).__name__}")
 
-    D = _Decoder(dec, shard, shadow=bool(sparse and bf16 and optimizer is not None))
+    spec = getattr(S, "speculated", None) if S is not None else None
+    D = spec[0] if spec is not None else _Decoder(dec, shard, shadow=bool(sparse and bf16 and optimizer is not None))
     N = Bn * L * d
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"
@@ -544,14 +556,15 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         # partial reconstruction layer-major [L, B, d].  Launched first (the host has just read the selection's outcome flag
         # and the launch queue is empty); the dead-feature update and its tiny all-reduce follow, and only then are the
         # all-reduces of the layer groups queued on RCCL's stream — no small collective waits behind them
-        r_lm = ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True, w_bf16=D.shadow, layer_major=True)
+        r_lm = spec[2] if spec is not None and spec[1] else ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True,
+                                                                                   w_bf16=D.shadow, layer_major=True)
         dead, dead_cnt = dead_features()
         groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
         waits = [shard.all_reduce_sum_async(r_lm[lo:hi]) for lo, hi in groups]
         r = None
     else:
         if sparse:
-            r = D.sparse_fwd(S)
+            r = D._reduce(spec[2]) if spec is not None and not spec[1] else D.sparse_fwd(S)
         elif fused_ops is not None:
             r = D.fwd(None, feat_op=fused_ops[0])
         else:
