@@ -97,6 +97,17 @@ SELECT_MARGIN = 0.9
 ADAPTIVE_SELECT_MARGIN = True
 #: queue the decoder's gather forward before the host reads the fused selection's outcome flag
 SPECULATIVE_FORWARD = True
+#: streams the decoder's weight passes alternate over when the matrices are small (CLT_ROWPASS_STREAMS=1: off, for A/B runs)
+ROW_PASS_STREAMS = int(os.environ.get("CLT_ROWPASS_STREAMS", "2"))
+ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below which a pass is "short"
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
@@ -340,11 +351,26 @@ class _Decoder:
             g2 = ops.cast_bf16(g2) if g2 is not None else None
         second = (S2, S2.csc_val, g2) if S2 is not None else None
         todo = list(enumerate(zip(self.names(), self.W32)))
-        for l, (name, w) in (reversed(todo) if slabs is not None else todo):
+        # the passes of different matrices are independent (own rows, own dot slots): alternating them over two streams lets
+        # one pass's tail overlap the next one's ramp (not while bench.py's roofline pass times the launches one by one)
+        # — measured: 8-way shard of the headline (passes of 35..180 us) 2.67 -> 2.61 ms/step; whole model (850 us passes)
+        # 15.60 -> 15.87, two bandwidth-bound kernels only get in each other's way: short passes only
+        small = sum(w.numel() for w in self.W32) < ROW_PASS_SMALL * len(self.W32)
+        two = ROW_PASS_STREAMS > 1 and small and ops.TIMING is None and len(todo) > 1
+        if two:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        for idx, (l, (name, w)) in enumerate(reversed(todo) if slabs is not None else todo):
             kw = dict(dots=dots, dots2=dots2, second=second, dot_slot=-1 if self.clt else 0)
             if slabs is not None:
                 g = slabs(l)
                 kw["src_slab"] = True
+                if two and idx % 2 == 1:         # (the slab was produced on the main stream)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
             if extra is not None:
                 kw["extra"] = (extra[0][name].view(-1, w.shape[-1]), extra[1], None)
             if fused is not None:
@@ -353,7 +379,15 @@ class _Decoder:
                     kw["shadow"] = self.shadows()[l]
             else:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
-            ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+            if two and idx % 2 == 1:
+                with torch.cuda.stream(side):
+                    ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+            else:
+                ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+        if two:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
         dval = ops.sparse_reduce_dots(dots, S, self.clt)
         dval2 = ops.sparse_reduce_dots(dots2, S2, self.clt) if S2 is not None else None
         return dval, dval2
