@@ -432,7 +432,20 @@ def _list_capacity(nl, Bn, L, F):
     return max(1, min(nl.k, F) * Bn * L)
 
 
+class _VoidAttempt(Exception):
+    """The fused encoder+select attempt of this step did not hold (learnt late, see _settle): run the step again unfused."""
+
+
 def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, sparse: Optional[bool] = None) -> Dict[str, object]:
+    try:
+        return _training_step(mod, batch, batch_idx, optimizer, sparse)
+    except _VoidAttempt:
+        # nothing of the module's state was touched: the forward, the exchange and the loss computed from the void lists only
+        # wrote scratch buffers.  The sparsifier's k-th value is reset, so this pass takes the unfused GEMM + selection.
+        return _training_step(mod, batch, batch_idx, optimizer, sparse)
+
+
+def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, sparse: Optional[bool] = None) -> Dict[str, object]:
     """Returns {"loss": 0-dim fp32 tensor, "terms": {name: tensor}, "grads": {param_name: tensor},
     "dead": uint8 [L,F], ...}.  `mod` is a CrossLayerTranscoderModule (or subclass).
 
@@ -495,6 +508,7 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     theta = None
     feat = S = pre = fused_ops = dpreT = None
     batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
+    pending = None                               # deferred host read of the fused selection's outcome (see _settle_select)
     probe = getattr(nl, "_kth_probe", None)
     if probe is not None and probe.value():
         # the last unfused selection ended in its exhaustive fallback, which leaves no k-th key behind: a fused attempt
@@ -518,14 +532,32 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
 
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
                                           nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
-                                          speculate=_spec_fwd if SPECULATIVE_FORWARD else None)
+                                          speculate=_spec_fwd if SPECULATIVE_FORWARD else None, defer=SPECULATIVE_FORWARD)
         STATS["fused_select_steps"] += 1
-        if S is not None:
+
+        def _settle_select():
+            """The step's one host read: did the bound hold?  Asked as late as possible — before the first kernel that
+            changes module state (dead-feature counters, weights) — so that the forward, the exchange and the first loss
+            kernel are already queued behind the selection and the GPU does not idle while the host waits."""
+            nonlocal pending
+            pending = None
+            if S.confirm():
+                nl._kth = kth
+                return
+            nl._kth = None
+            STATS["select_fallbacks"] += 1
+            if drift is not None:
+                drift[:nseg] = 0.1               # the bound did not hold: back to the floor for ~30 steps, then tighten again
+            raise _VoidAttempt()
+
+        if SPECULATIVE_FORWARD:
+            pending = _settle_select
+        elif S is not None:
             nl._kth = kth
         else:
             STATS["select_fallbacks"] += 1
             if drift is not None:
-                drift[:nseg] = 0.1               # the bound did not hold: back to the floor for ~30 steps, then tighten again
+                drift[:nseg] = 0.1
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
     # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their
@@ -592,7 +624,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
         # all-reduces of the layer groups queued on RCCL's stream — no small collective waits behind them
         r_lm = spec[2] if spec is not None and spec[1] else ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True,
                                                                                    w_bf16=D.shadow, layer_major=True)
-        dead, dead_cnt = dead_features()
+        if pending is None:
+            dead, dead_cnt = dead_features()
         groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
         waits = [shard.all_reduce_sum_async(r_lm[lo:hi]) for lo, hi in groups]
         r = None
@@ -603,7 +636,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
             r = D.fwd(None, feat_op=fused_ops[0])
         else:
             r = D.fwd(feat)
-        dead, dead_cnt = dead_features()
+        if pending is None:
+            dead, dead_cnt = dead_features()
     g16 = b_grad = slabs = None
     fm = ops.mse_bf16_colsum(r, mlp_out, ost.mean, ost.std) if (FUSE_MSE_BF16 and lists_only and bf16 and kind == "base"
                                                                  and not pipelined) else None
@@ -632,6 +666,8 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
                         ops.column_sum(gl, b_grad[ll])
                         g_lm[ll].copy_(ops.cast_bf16(gl) if bf16 else gl)
             return g_lm[l]
+        if pending is not None:
+            slabs(L - 1)                                 # (first group's loss kernel queued before the host read below)
         terms = {}
     elif fm is not None:                     # loss + bf16 gradient rows + decoder bias gradient in one pass, no fp32 gradient
         loss_sum, g16, b_grad = fm
@@ -640,6 +676,9 @@ def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spar
     else:
         loss_sum, g, ys = ops.mse(r, mlp_out, ost.mean, ost.std, True, want_ys)
         terms = {"mse": (loss_sum[0] / N).float()}
+    if pending is not None:
+        pending()                                        # raises _VoidAttempt when the fused selection did not hold
+        dead, dead_cnt = dead_features()
     terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
     out = StepOutput(terms=terms, grads=grads, dead=dead)
     out["grad_scale"] = ops.GRAD_SCALE           # out["grads"] carry this factor (1.0 outside fp16 mode)

@@ -763,7 +763,7 @@ def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wei
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
     __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
-                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth", "tie_radix", "speculated")
+                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth", "tie_radix", "speculated", "confirm")
 
 
 def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
@@ -945,7 +945,7 @@ def select_lists_sharded(x: torch.Tensor, k: int, mode: int, shard, threshold: O
 
 def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor], k: int, mode: int, prev_T: torch.Tensor,
                          margin: float, threshold: Optional[torch.Tensor], e: float, shard=None, cap: Optional[int] = None,
-                         drift: Optional[torch.Tensor] = None, speculate=None):
+                         drift: Optional[torch.Tensor] = None, speculate=None, defer: bool = False):
     """Encoder forward fused with the BatchTopK / PerLayerBatchTopK selection: the bf16 NT GEMM's epilogue appends the
     candidates (>= margin * last step's k-th value, `prev_T` int32 keys [S]) and the pre-activation tensor is never
     written.  Returns (lists, T) — T = int32 keys [S] of this step's exact k-th values — or (None, None) when the
@@ -954,7 +954,10 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     0.98 as far as the observed step-to-step change of the k-th value allows (clt_select_lists_ext_f32).
     speculate(lists): called after the list construction has been queued and BEFORE the host learns whether the attempt held —
     for work that only reads the lists and writes fresh buffers (the decoder's gather forward); its result is kept in
-    lists.speculated.  After a void attempt the lists are empty (row offsets all zero), so such work is harmless and discarded."""
+    lists.speculated.  After a void attempt the lists are empty (row offsets all zero), so such work is harmless and discarded.
+    defer: return (lists, T) at once, the host read postponed to lists.confirm() -> bool (False: void; everything computed
+    from the lists must then be thrown away) — the caller keeps queueing work that mutates no state and asks before the
+    first kernel that does."""
     from .parallel import run_sharded_selection
     Bn, L, d = xs.shape
     F = Wt.shape[1]
@@ -993,21 +996,29 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     # completes while stage 6 (emit + list construction) is still running and the launch queue never drains
     ev = torch.cuda.Event()
     ev.record()
-    if speculate is not None:
+    if speculate is not None or defer:
         s.row_start.zero_()                  # (a void attempt emits nothing: speculative readers then see no entries)
+        s.col_start.zero_()
     stages(6, 6)
     spec = speculate(s) if speculate is not None else None
     side, host = _flag_reader(xs.device)
     with torch.cuda.stream(side):
         side.wait_event(ev)
         host.copy_(fb, non_blocking=True)
-    side.synchronize()
-    if int(host) != 0:
-        return None, None
     T = i32(off[6], 4 * S).view(S, 4)[:, 0].clone()
     s.used_fallback = fb
     s.kth = T
     s.speculated = spec
+
+    def confirm() -> bool:
+        side.synchronize()
+        return int(host) == 0
+
+    s.confirm = confirm
+    if defer:
+        return s, T
+    if not confirm():
+        return None, None
     return s, T
 
 
