@@ -128,12 +128,11 @@ struct RowPassArgs {
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
 // 16-byte lanes).  CW > 1 (long rows, e.g. d = 4096): one row per block, wave c owns the c-th 1024-float chunk —
 // keeps the per-lane state at NT = 4 (high occupancy) and combines the per-entry dots through LDS in wave order.
-template <int NT, bool VEC, int CW, bool F16 = false>
-__global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
+template <int NT, bool VEC, int CW, bool F16>
+__device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r) {
     constexpr int W = VEC ? 4 : 1;
     __shared__ float shdot[2][CW];
     const int wave = threadIdx.x >> 6;
-    const int r = CW == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (r >= a.rows) return;
     const int lane = threadIdx.x & 63;
     const int cb = CW == 1 ? 0 : wave * NT * 64 * W;          // first element of this wave's chunk
@@ -279,6 +278,34 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
             if (a.shadow) a.shadow[ro + o] = (uint16_t)pack16<F16>(wv[t][0], 0.0f);
         }
     }
+}
+
+template <int NT, bool VEC, int CW, bool F16 = false>
+__global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
+    row_pass_body<NT, VEC, CW, F16>(a, CW == 1 ? blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
+}
+
+// Several weight matrices in ONE launch (clt_sparse_row_pass_group_f32): the rows of the matrices are laid end to end over
+// the grid; a wave finds its matrix in the (at most 16 entries long) table and runs the ordinary pass with that matrix's
+// pointers, source and layer.  On a feature shard the per-matrix launches are 35..180 us long and spend a fifth of that
+// ramping up and draining.
+constexpr int RP_GROUP_MAX = 16;
+struct RowPassGroup {
+    int n; int row_end[RP_GROUP_MAX];                     // cumulative row counts
+    float* W[RP_GROUP_MAX]; float* m[RP_GROUP_MAX]; float* v[RP_GROUP_MAX]; uint16_t* shadow[RP_GROUP_MAX];
+    const float* src[RP_GROUP_MAX]; int src_layer[RP_GROUP_MAX];
+};
+template <int NT, bool F16>
+__global__ __launch_bounds__(TPB) void row_pass_group_kernel(RowPassArgs a, RowPassGroup g) {
+    int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (r >= g.row_end[g.n - 1]) return;
+    int i = 0;
+    while (r >= g.row_end[i]) ++i;
+    i = __builtin_amdgcn_readfirstlane(i);                // (one row per wave: the matrix index is wave-uniform)
+    r -= i ? g.row_end[i - 1] : 0;
+    a.W = g.W[i]; a.m = g.m[i]; a.v = g.v[i]; a.shadow = g.shadow[i]; a.src = g.src[i]; a.src_layer = g.src_layer[i];
+    a.rows = g.row_end[i] - (i ? g.row_end[i - 1] : 0);
+    row_pass_body<NT, true, 1, F16>(a, r);
 }
 
 // dval[p] = sum_{s < nslots(p)} dots[s*stride + p], nslots = L - layer(column of p) (cross-layer) or 1
@@ -480,6 +507,46 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
         else return CLT_ERR_RANGE;
     }
 #undef RP
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, float* const* v, uint16_t* const* shadow,
+                                   const int* rows, const int* src_layer, const void* const* src, int d, int F, int L,
+                                   const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
+                                   double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
+                                   int src_bf16, void* stp) {
+    if (nmat <= 0 || d <= 0 || F <= 0 || L <= 0 || step < 1 || !W || !m || !v || !rows || !src_layer || !src) return CLT_ERR_SHAPE;
+    if (nmat > RP_GROUP_MAX) return 1;
+    const int chunks = (d + 255) / 256;
+    if (d % 4 || chunks > 4) return 1;                       // (one wave per row with 16-byte lanes only: the caller launches per matrix)
+    RowPassArgs a = {};
+    RowPassGroup g = {};
+    g.n = nmat;
+    long total = 0;
+    for (int i = 0; i < nmat; ++i) {
+        if (rows[i] <= 0 || src_layer[i] < 0 || !W[i] || !m[i] || !v[i] || !src[i]) return CLT_ERR_SHAPE;
+        if (!aligned16(W[i]) || !aligned16(m[i]) || !aligned16(v[i]) || (shadow && shadow[i] && (reinterpret_cast<uintptr_t>(shadow[i]) & 7)) ||
+            (src_bf16 ? (reinterpret_cast<uintptr_t>(src[i]) & 7) != 0 : !aligned16(src[i]))) return 1;
+        total += rows[i];
+        if (total > 0x7fffffffL) return CLT_ERR_RANGE;
+        g.row_end[i] = (int)total;
+        g.W[i] = W[i]; g.m[i] = m[i]; g.v[i] = v[i]; g.shadow[i] = shadow ? shadow[i] : nullptr;
+        g.src[i] = static_cast<const float*>(src[i]); g.src_layer[i] = src_layer[i];
+    }
+    a.d = d; a.F = F; a.L = L; a.col0 = 0; a.col_start = col_start; a.tok = tok; a.coef = coef;
+    a.dot_out = dot_out; a.dot_stride = dot_stride; a.dot_slot_base = -1; a.src_bf16 = src_bf16;
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    a.lr = (float)lr; a.omb1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.wd = (float)weight_decay; a.step_size = (float)(lr / bc1); a.isb2 = (float)(1.0 / sqrt(bc2)); a.adamw = adamw;
+    hipStream_t st = as_stream(stp);
+    const dim3 grid((unsigned)((total + 3) / 4));
+#define RPG(NT_)                                                                                             \
+    do {                                                                                                      \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_group_kernel<NT_, true>), grid, dim3(TPB), 0, st, a, g); \
+        else hipLaunchKernelGGL((row_pass_group_kernel<NT_, false>), grid, dim3(TPB), 0, st, a, g);           \
+    } while (0)
+    if (chunks <= 1) RPG(1); else if (chunks <= 2) RPG(2); else if (chunks <= 3) RPG(3); else RPG(4);
+#undef RPG
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 

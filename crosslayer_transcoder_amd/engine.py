@@ -100,6 +100,8 @@ SPECULATIVE_FORWARD = True
 #: streams the decoder's weight passes alternate over when the matrices are small (CLT_ROWPASS_STREAMS=1: off, for A/B runs)
 ROW_PASS_STREAMS = int(os.environ.get("CLT_ROWPASS_STREAMS", "2"))
 ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below which a pass is "short"
+#: short passes of one layer group in one launch (CLT_GROUP_ROW_PASSES=0: off, for A/B runs)
+GROUP_ROW_PASSES = os.environ.get("CLT_GROUP_ROW_PASSES", "1") != "0"
 _side_streams = {}
 
 
@@ -337,7 +339,7 @@ class _Decoder:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
             ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
 
-    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None, slabs=None):
+    def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None, slabs=None, groups=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.
         Returns (dval [S.cap], dval2 [S2.cap] or None).  extra = ({name: compact dW}, map): dense gradient of the
         compacted aux pass, added to the mapped rows.  slabs (cross-layer decoder, pipelined exchange): slabs(l) returns
@@ -356,6 +358,32 @@ class _Decoder:
         # — measured: 8-way shard of the headline (passes of 35..180 us) 2.67 -> 2.61 ms/step; whole model (850 us passes)
         # 15.60 -> 15.87, two bandwidth-bound kernels only get in each other's way: short passes only
         small = sum(w.numel() for w in self.W32) < ROW_PASS_SMALL * len(self.W32)
+        if (GROUP_ROW_PASSES and small and self.clt and fused is not None and extra is None and S2 is None and len(todo) > 1
+                and len(todo) <= 16):
+            # short passes (feature shards): the matrices of a layer group — of the whole decoder without the pipelined
+            # exchange — go through ONE launch (clt_sparse_row_pass_group_f32)
+            kws = [fused.begin_fused(w) for _, (_, w) in todo]
+            same = all(k["adam"] == kws[0]["adam"] for k in kws)
+            sh = self.shadows() if self.shadow else None
+            done_all = same
+            # (one stream: alternating the group launches over two streams measured slower, 2.555 -> 2.588 ms)
+            for gi, (lo, hi) in enumerate(groups if slabs is not None else [(0, len(todo))]):
+                if not done_all:
+                    break
+                ls = list(range(hi - 1, lo - 1, -1)) if slabs is not None else list(range(lo, hi))
+                srcs = [slabs(l) for l in ls] if slabs is not None else [g] * len(ls)
+                ok = ops.sparse_row_pass_group([self.W32[l] for l in ls], S, S.csc_val, srcs, ls, adam=kws[0]["adam"],
+                                               ms=[kws[l]["m"] for l in ls], vs=[kws[l]["v"] for l in ls],
+                                               shadows=[sh[l] for l in ls] if sh is not None else None, dots=dots,
+                                               src_slab=slabs is not None)
+                if not ok:
+                    assert gi == 0                       # (a shape test: it fails on the first launch or never)
+                    done_all = False
+            if done_all:
+                return ops.sparse_reduce_dots(dots, S, self.clt), None
+            begun = dict(zip((l for l, _ in todo), kws))
+        else:
+            begun = None
         two = ROW_PASS_STREAMS > 1 and small and ops.TIMING is None and len(todo) > 1
         if two:
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
@@ -374,7 +402,7 @@ class _Decoder:
             if extra is not None:
                 kw["extra"] = (extra[0][name].view(-1, w.shape[-1]), extra[1], None)
             if fused is not None:
-                kw.update(fused.begin_fused(w))
+                kw.update(begun[l] if begun is not None else fused.begin_fused(w))
                 if self.shadow:
                     kw["shadow"] = self.shadows()[l]
             else:
@@ -756,7 +784,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             extra_dec = (gc, cmap)
             extra_enc = (dWt_c.view(-1, d), cmap, ops.column_sum(dpre_c).view(-1))
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
-                                   slabs=slabs)
+                                   slabs=slabs, groups=groups if pipelined else None)
         if pipelined:
             terms["mse"] = (loss_parts.sum() / N).float()
             loss = terms["mse"]

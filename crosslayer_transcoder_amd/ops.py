@@ -1157,6 +1157,36 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), _stream())
 
 
+def sparse_row_pass_group(Ws, s: SparseLists, coef, srcs, layers, *, adam, ms, vs, shadows=None, dots=None, src_slab=False) -> bool:
+    """clt_sparse_row_pass_group_f32: the fused-Adam row pass of several matrices of one cross-layer decoder in ONE launch
+    (matrix i: rows Ws[i].numel() / d, target layer layers[i], gather source srcs[i] — a [B, L, d] tensor, or with
+    `src_slab` that layer's slab [B, d]).  False when the shape does not qualify (the caller launches per matrix)."""
+    import ctypes as C
+    n = len(Ws)
+    d = Ws[0].shape[-1]
+    src_bf16 = srcs[0].dtype in _DT16
+    ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    for w, m, v, x in zip(Ws, ms, vs, srcs):
+        _chk(w); _chk(m); _chk(v); _chk(x, srcs[0].dtype)
+    rows = (C.c_int * n)(*[w.numel() // d for w in Ws])
+    if src_slab:             # (see sparse_row_pass: L = 1 and the base moved back by layer * d elements)
+        sp = (C.c_void_p * n)(*[x.data_ptr() - l * d * x.element_size() for x, l in zip(srcs, layers)])
+        src_L = 1
+    else:
+        sp, src_L = ptrs(srcs), s.L
+    payload = [(w.numel() // d, d, 0, l, True, 2 if src_bf16 else 4, shadows is not None) for w, l in zip(Ws, layers)]
+    rc = _timed_raw("row_pass_group", payload, "clt_sparse_row_pass_group_f32", n, ptrs(Ws), ptrs(ms), ptrs(vs),
+                    ptrs(shadows) if shadows is not None else None, rows, (C.c_int * n)(*layers), sp, d, s.F, src_L, s.col_start.data_ptr(),
+                    s.csc_tok.data_ptr(), _chk(coef).data_ptr(), dots.data_ptr() if dots is not None else None, s.cap, float(adam["lr"]),
+                    float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"]), float(adam["weight_decay"]), int(adam["adamw"]),
+                    int(adam["step"]), int(src_bf16), _stream())
+    if rc == 1:
+        return False
+    if rc != 0:
+        raise CltError("clt_sparse_row_pass_group_f32", rc)
+    return True
+
+
 def compact_columns(dead_u8: torch.Tensor):
     """Dead-column compaction maps (clt_compact_columns).  Returns (n_pad, idx int32 [L, n_pad], map int32 [L*F]) or
     None when no feature is dead.  One host read (the per-layer counts)."""

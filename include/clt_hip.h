@@ -383,6 +383,18 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
                             const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
                             void* stream);
+/* Several weight matrices of one decoder in ONE launch of the same pass (Adam in place; no gradient output, second list,
+ * compact contribution or row term): matrix i has rows[i] rows of d floats (row r <-> CSC column r), gathers from src[i]
+ * (a [B][L][d] tensor, layer src_layer[i]; fp32, or 16-bit when src_bf16) and writes its dots to slot
+ * src_layer[i] - r / F of dot_out.  W / m / v / shadow / rows / src_layer / src: HOST arrays of nmat entries (nmat <= 16).
+ * For feature shards, whose per-matrix launches are too short to reach the HBM rate.  Returns 1 when the shape does not
+ * qualify (d % 4, d > 1024, alignment): the caller then launches clt_sparse_row_pass_f32 per matrix. */
+int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, float* const* v, uint16_t* const* shadow,
+                                  const int* rows, const int* src_layer, const void* const* src, int d, int F, int L,
+                                  const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
+                                  double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
+                                  int src_bf16, void* stream);
+
 /* Column compaction for the TopK-aux pass (clt_lightning.py:539-553: top k_aux among the DEAD features, second decoder
  * pass): the dead columns are gathered so that the pass runs as a dense sub-problem of n_pad columns per layer.
  *   clt_compact_columns: counts[l] = number of dead features of layer l; when idx != NULL also

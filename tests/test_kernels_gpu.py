@@ -599,3 +599,38 @@ def test_mse_bf16_colsum_one_pass(ops, B, L, d):
     assert torch.allclose(loss2, loss, rtol=1e-12, atol=0)
     ref = g.double().sum(0).float()
     assert torch.allclose(colsum, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("slab,bf16", [(False, False), (True, True), (False, True)])
+def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16):
+    """clt_sparse_row_pass_group_f32 (all matrices of a cross-layer decoder in one launch) against one
+    clt_sparse_row_pass_f32 launch per matrix: same arithmetic per row, so weights, moments, shadows and dots are bit-identical."""
+    B, L, F, d = 37, 4, 96, 40
+    feat = _sparse_features(B, L, F, 6, seed=3)
+    S = ops.sparse_build(feat.to(DEV), 6 * B * L)
+    g = _rand(B, L, d, seed=5).to(DEV)
+    src = ops.cast_bf16(g) if bf16 else g
+    g_lm = src.permute(1, 0, 2).contiguous()                     # layer-major slabs [L, B, d]
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False, step=3)
+    res = []
+    for grouped in (False, True):
+        Ws = [_rand(l + 1, F, d, seed=20 + l, scale=0.05).to(DEV) for l in range(L)]
+        ms = [_rand(l + 1, F, d, seed=30 + l, scale=0.01).to(DEV) for l in range(L)]
+        vs = [_rand(l + 1, F, d, seed=40 + l, scale=0.01).to(DEV).abs() for l in range(L)]
+        shs = [torch.zeros(l + 1, F, d, dtype=torch.bfloat16, device=DEV) for l in range(L)]
+        dots = torch.zeros(L, S.cap, device=DEV)
+        ls = list(range(L - 1, -1, -1))
+        if grouped:
+            srcs = [g_lm[l] for l in ls] if slab else [src] * L
+            assert ops.sparse_row_pass_group([Ws[l] for l in ls], S, S.csc_val, srcs, ls, adam=hp, ms=[ms[l] for l in ls],
+                                             vs=[vs[l] for l in ls], shadows=[shs[l] for l in ls], dots=dots, src_slab=slab)
+        else:
+            for l in ls:
+                ops.sparse_row_pass(Ws[l], S, S.csc_val, g_lm[l] if slab else src, 0, l, adam=hp, m=ms[l], v=vs[l], shadow=shs[l],
+                                    dots=dots, dot_slot=-1, src_slab=slab)
+        res.append((Ws, ms, vs, shs, dots))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(res[0][4], res[1][4])
+    assert not torch.equal(res[0][0][L - 1], _rand(L, F, d, seed=20 + L - 1, scale=0.05).to(DEV))     # (the pass did move the weights)
