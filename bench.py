@@ -135,7 +135,10 @@ def roofline(timing, mod, args, world):
       + 4*rows  (column offsets)
     `achieved` = sum of those bytes over the instrumented launches / sum of their HIP-event durations.  The events are
     recorded in a separate short pass AFTER the timed loop (same stream, same batches)."""
-    ev = timing.get("row_pass", [])
+    # (feature shards launch the matrices of a layer group together, clt_sparse_row_pass_group_f32: one event pair, several
+    # matrices' bytes)
+    single, grouped = timing.get("row_pass", []), timing.get("row_pass_group", [])
+    ev = single + grouped
     lists = mod.last_step.get("lists")
     if not ev or lists is None:            # dense regime: the MFMA GEMMs dominate
         gv = timing.get("gemm", [])
@@ -149,15 +152,15 @@ def roofline(timing, mod, args, world):
                 "gemm_ms_per_step": ms / timing["#steps"]}
     # the lists of the LAST instrumented step price its launches; earlier steps' launches use the same per-launch figure
     col_start = lists.col_start.cpu().long()
-    per_step = len(ev) // timing["#steps"]
-    nbytes = ms = 0.0
-    for i, (e0, e1, (rows, d, col0, src_layer, fused, src_bytes, shadow)) in enumerate(ev):
-        ms += e0.elapsed_time(e1)
-        if i < len(ev) - per_step:
-            continue
-        hits = int(col_start[col0 + rows] - col_start[col0])
-        per_row = (24 if fused else 4) * d + (2 * d if shadow else 0) + 4
-        nbytes += rows * per_row + hits * (src_bytes * d + 12)
+    n = timing["#steps"]
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    last = [[p] for _, _, p in single[len(single) - len(single) // n:]] + [m for _, _, m in grouped[len(grouped) - len(grouped) // n:]]
+    nbytes = 0.0
+    for mats in last:
+        for rows, d, col0, src_layer, fused, src_bytes, shadow in mats:
+            hits = int(col_start[col0 + rows] - col_start[col0])
+            per_row = (24 if fused else 4) * d + (2 * d if shadow else 0) + 4
+            nbytes += rows * per_row + hits * (src_bytes * d + 12)
     nbytes *= timing["#steps"]             # (hit counts differ by < 0.1 % between steps: k*B*L entries in total either way)
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic = None
