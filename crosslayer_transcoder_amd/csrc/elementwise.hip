@@ -173,7 +173,8 @@ __global__ void mse_kernel(const float* __restrict__ r, const float* __restrict_
 // loss sum, d(loss)/d(recons) as the bf16 rows the weight pass gathers, and its column sums (the decoder bias gradient).
 // One pass instead of mse + cast + column_sum, and no fp32 gradient tensor.  Block = 64 rows x 256 columns (a wave per
 // row, 4 columns per lane); part_c: [gridDim.y][n] column partials, part_l: [gridDim.x * gridDim.y] loss partials.
-constexpr int MF_R = 64;
+constexpr int MF_R = 64;                                // (32 / 16 / 8 rows per block measured equal or slower on a cold cache)
+constexpr int MF_U = MF_R / 4 < 8 ? MF_R / 4 : 8;      // rows a thread has in flight
 template <bool F16>
 __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
                                                               const float* __restrict__ mean, const float* __restrict__ stdv, int rows,
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
     float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     double acc = 0.0;
     // (8 rows = 16 loads of 16 bytes in flight per thread)
-    for (int i0 = 0; i0 < MF_R / 4; i0 += 8) {
-        float4 rv[8], yv[8];
+    for (int i0 = 0; i0 < MF_R / 4; i0 += MF_U) {
+        float4 rv[MF_U], yv[MF_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < MF_U; ++u) {
             const int row = r0 + w + 4 * (i0 + u);
             if (cin && row < rows) {
                 rv[u] = *reinterpret_cast<const float4*>(r + (long)row * n + col);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
         // even lane stores 8 columns of row u, the odd lane 8 columns of row u + 1; 8-byte stores run at about half the rate)
         const bool wide = (n & 7) == 0 && (rows & (MF_R - 1)) == 0 && (reinterpret_cast<uintptr_t>(g16) & 15) == 0;
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
+        for (int u = 0; u < MF_U; u += 2) {
             uint32_t q[2][2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
