@@ -96,7 +96,7 @@ SELECT_MARGIN = 0.9
 #: allows (device-side peak-hold of |T_t / T_{t-1} - 1|, clt_select_lists_ext_f32's drift state): fewer candidates in the epilogue
 ADAPTIVE_SELECT_MARGIN = True
 #: queue the decoder's gather forward before the host reads the fused selection's outcome flag
-SPECULATIVE_FORWARD = True
+SPECULATIVE_FORWARD = os.environ.get("CLT_SPEC_FWD", "1") != "0"
 #: streams the decoder's weight passes alternate over when the matrices are small (CLT_ROWPASS_STREAMS=1: off, for A/B runs)
 ROW_PASS_STREAMS = int(os.environ.get("CLT_ROWPASS_STREAMS", "2"))
 ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below which a pass is "short"

@@ -216,6 +216,7 @@ class CrossLayerTranscoderModule(_Base):
         """fwd + bwd + Adam with no autograd bookkeeping.  `stepper`: the object whose step() is called for the
         parameters the backward pass did not update itself (Lightning's optimizer wrapper, which also counts
         global_step; default: `optimizer`)."""
+        optimizer.track_steps = get_precision() == "fp16"
         out = self.compute_step(batch, batch_idx, optimizer if fuse_adam else None, sparse)
         params = self._named_model_params()
         for n, p in params.items():

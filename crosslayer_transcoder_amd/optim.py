@@ -21,7 +21,10 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
         self._row_terms = {}
-        self._stepped = []          # parameters whose step count moved since the last commit() (fp16 loss scaling)
+        #: fp16 loss scaling only (set by the training step): remember the parameters whose step count moved, so that
+        #: commit(skipped=True) can give the counts back after a step the kernels skipped
+        self.track_steps = False
+        self._stepped = []
 
     def add_row_term(self, p, dnorm, sq):
         """The next step() adds (dnorm[r] / sqrt(sq[r])) * p[r, :] to p's gradient inside the update kernel (the
@@ -50,7 +53,8 @@ class FusedAdam(torch.optim.Optimizer):
         group = self._group_of(p)
         st = self._state(p)
         st["step"] += 1
-        self._stepped.append(p)
+        if self.track_steps:
+            self._stepped.append(p)
         b1, b2 = group["betas"]
         return dict(adam=dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                               adamw=group["adamw"], step=st["step"]), m=st["exp_avg"], v=st["exp_avg_sq"])
@@ -76,7 +80,8 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 st = self._state(p)
                 st["step"] += 1
-                self._stepped.append(p)
+                if self.track_steps:
+                    self._stepped.append(p)
                 g = _same_layout(p.grad, p)
                 ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
                          group["weight_decay"], group["adamw"], None, self._row_terms.pop(id(p), None))
