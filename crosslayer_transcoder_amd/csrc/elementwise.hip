@@ -478,10 +478,10 @@ __device__ __forceinline__ void store_rowpair16(uint16_t* __restrict__ out, long
 
 // four consecutive elements of an activation tensor held as fp32 (BF = false) or bf16 (BF = true: the dense bf16 regime's
 // GEMMs can leave pre-activations and feature gradients as bf16, clt_gemm_bf16_nt_out16)
-template <bool BF> __device__ __forceinline__ float4 act_load4(const void* __restrict__ base, long idx) {
-    if (BF) {
+template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4(const void* __restrict__ base, long idx) {
+    if (BF) {           // 16-bit activations in the active operand format
         const ushort4 h = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(base) + idx);
-        return make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+        return make_float4(cvt16<F16>(h.x), cvt16<F16>(h.y), cvt16<F16>(h.z), cvt16<F16>(h.w));
     }
     return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
 }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
         for (int u = 0; u < 4; ++u) {
             const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
             vv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (cin && row < rows) vv[u] = act_load4<XB>(x, (long)row * n + col);
+            if (cin && row < rows) vv[u] = act_load4<XB, F16>(x, (long)row * n + col);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -635,8 +635,8 @@ __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __r
                 const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
                 v4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); g4[u] = v4[u];
                 if (cin && row < rows) {
-                    v4[u] = act_load4<XB>(x, (long)row * n + col);
-                    g4[u] = act_load4<GB>(dfm, (long)row * n + col);
+                    v4[u] = act_load4<XB, F16>(x, (long)row * n + col);
+                    g4[u] = act_load4<GB, F16>(dfm, (long)row * n + col);
                 }
             }
 #pragma unroll
@@ -1032,7 +1032,7 @@ int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int row
     if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
     const dim3 grid((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R);
 #define JF(XB_, F_) hipLaunchKernelGGL((jumprelu_fwd_bf16_kernel<XB_, F_>), grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired)
-    if (clt_host_state.fp16) { if (x_bf16) return CLT_ERR_SHAPE; JF(false, true); }        // (16-bit activations: bf16 operand mode only)
+    if (clt_host_state.fp16) { if (x_bf16) JF(true, true); else JF(false, true); }
     else if (x_bf16) JF(true, false);
     else JF(false, false);
 #undef JF
@@ -1053,13 +1053,11 @@ int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, co
     double* ps = (double*)((char*)ws + align_up((size_t)3 * gy * n * sizeof(float), 16));
 #define JL2(XB_, GB_, TH_, F_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_, F_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, \
                                                  dfm, bw, lamB, c, coefBL, dpreT, part, ps, rows, n)
-#define JL(XB_, GB_) do { if (use_tanh) JL2(XB_, GB_, true, false); else JL2(XB_, GB_, false, false); } while (0)
-    if (clt_host_state.fp16) {                                  // (16-bit activations: bf16 operand mode only)
-        if (x_bf16 || dfm_bf16) return CLT_ERR_SHAPE;
-        if (use_tanh) JL2(false, false, true, true); else JL2(false, false, false, true);
-    }
-    else if (x_bf16) { if (dfm_bf16) JL(true, true); else JL(true, false); }
-    else { if (dfm_bf16) JL(false, true); else JL(false, false); }
+#define JL(XB_, GB_, F_) do { if (use_tanh) JL2(XB_, GB_, true, F_); else JL2(XB_, GB_, false, F_); } while (0)
+#define JLF(F_) do { if (x_bf16) { if (dfm_bf16) JL(true, true, F_); else JL(true, false, F_); } \
+                     else { if (dfm_bf16) JL(false, true, F_); else JL(false, false, F_); } } while (0)
+    if (clt_host_state.fp16) JLF(true); else JLF(false);
+#undef JLF
 #undef JL2
 #undef JL
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * gy, 3, sums);

@@ -343,8 +343,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         typedef __attribute__((address_space(1))) u32x4 gvec;
                         u32x4 o;
-                        o[0] = pack_bf16x2(v0[0], v0[1]); o[1] = pack_bf16x2(v0[2], v0[3]);
-                        o[2] = pack_bf16x2(v1[0], v1[1]); o[3] = pack_bf16x2(v1[2], v1[3]);
+                        o[0] = pack16<F16>(v0[0], v0[1]); o[1] = pack16<F16>(v0[2], v0[3]);
+                        o[2] = pack16<F16>(v1[0], v1[1]); o[3] = pack16<F16>(v1[2], v1[3]);
                         *(gvec*)(C + (long)row * ldc + col) = o;
                     }
                 }
@@ -425,7 +425,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                               hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
     // bf16 result (C is then a bf16 array; ldc / sC in bf16 elements): 8-column alignment, no accumulate, no groups
-    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8 || clt_host_state.fp16)) return 1;
+    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
     const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
@@ -435,6 +435,15 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     if (nblk > 0x7fffffffL) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (clt_host_state.fp16 && out16) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
+                           lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(), SelEpi{}, Bseg, kts,
+                           (const GemmGroup*)nullptr);
+        CLT_LAUNCH_CHECK();
+        return CLT_OK;
+    }
     if (clt_host_state.fp16) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;

@@ -590,7 +590,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                  and (L * F) % 4 == 0)
     # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their
     # GEMMs as bf16 — the K = d_acts GEMMs are bound by their epilogue stores, and the consumers read half the bytes
-    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None and not fp16
+    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None
                  and not (sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0)))
     if S is None:
         pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), enc.b) if act16 else None
@@ -817,7 +817,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         sq = D.sqnorms()
         g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
         loss16 = fused_ops is not None or (S is not None and fuse_jump)
-        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS and not fp16))
+        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
         if loss16:
             sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                                   mod.pre_actv_loss / (Bn * L))

@@ -176,10 +176,10 @@ def encoder_fwd_out16(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tens
     autocast they are a bf16 tensor too).  None when the shape does not qualify for the fast kernel."""
     Bn, L, d = xs.shape
     F = Wt.shape[1]
-    _chk(xs, torch.bfloat16); _chk(Wt, torch.bfloat16)
+    _chk(xs, op16()); _chk(Wt, op16())
     if F % 8 or d % 8 or Bn * F < 256 * 256:
         return None
-    pre = torch.empty(Bn, L, F, dtype=torch.bfloat16, device=xs.device)
+    pre = torch.empty(Bn, L, F, dtype=op16(), device=xs.device)
     rc = _timed_raw("gemm", 2.0 * Bn * F * d * L, "clt_gemm_bf16_nt_out16", xs.data_ptr(), Wt.data_ptr(), pre.data_ptr(), Bn, F, d, L * d, d,
                     L * F, L, d, d * F, F, b.data_ptr() if b is not None else None, F, _stream())
     if rc == 1:
@@ -237,10 +237,10 @@ def plt_decoder_dgrad_out16(g: torch.Tensor, W: torch.Tensor) -> Optional[torch.
     """plt_decoder_dgrad with the feature gradient leaving as bf16 [B, L, F] (bf16 operands).  None: shape does not qualify."""
     Bn, L, d = g.shape
     F = W.shape[1]
-    _chk(g, torch.bfloat16); _chk(W, torch.bfloat16)
+    _chk(g, op16()); _chk(W, op16())
     if F % 8 or d % 8 or Bn * F < 256 * 256:
         return None
-    df = torch.empty(Bn, L, F, dtype=torch.bfloat16, device=g.device)
+    df = torch.empty(Bn, L, F, dtype=op16(), device=g.device)
     rc = _timed_raw("gemm", 2.0 * Bn * F * d * L, "clt_gemm_bf16_nt_out16", g.data_ptr(), W.data_ptr(), df.data_ptr(), Bn, F, d, L * d, d,
                     L * F, L, d, F * d, F, None, 0, _stream())
     if rc == 1:
@@ -264,7 +264,7 @@ def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor], out_bf16: bo
     for lp in range(L):
         ptrs += [_chk(Ws[l], op16()).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
     table = torch.tensor(ptrs, dtype=torch.int64).to(g.device)
-    df = torch.empty(Bn, L, F, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
+    df = torch.empty(Bn, L, F, dtype=op16() if out_bf16 else torch.float32, device=g.device)
     off = 0
     for lp in range(L):
         nseg = L - lp
@@ -658,7 +658,7 @@ def jumprelu_fwd_bf16(x, theta=None):
     """Dense bf16 regime: JumpReLU (theta=None: ReLU) straight to the GEMM operands.  x: fp32 or bf16 [B, L, F].
     Returns (feat bf16 [B, L, F], featT bf16 [L, F, B], fired uint8 [L, F])."""
     _chk(x, x.dtype)
-    assert x.dtype in (torch.float32, torch.bfloat16)
+    assert x.dtype in (torch.float32, op16())
     Bn, L, F = x.shape
     if theta is not None:
         _chk(theta)
@@ -666,7 +666,7 @@ def jumprelu_fwd_bf16(x, theta=None):
     feat = torch.empty(Bn, L, F, dtype=op16(), device=x.device)
     featT = torch.empty(L, F, Bn, dtype=op16(), device=x.device)
     fired = torch.empty(L, F, dtype=torch.uint8, device=x.device)
-    call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype == torch.bfloat16), theta.data_ptr() if theta is not None else None, Bn, L * F, feat.data_ptr(),
+    call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype in _DT16), theta.data_ptr() if theta is not None else None, Bn, L * F, feat.data_ptr(),
          featT.data_ptr(), fired.data_ptr(), _stream())
     return feat, featT, fired
 
@@ -675,7 +675,7 @@ def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c,
     """jumprelu_loss_bwd for the dense bf16 regime: returns (sums fp64 [3], dpreT bf16 [L, F, B], dbias fp32 [L, F],
     dtheta, dnorm) — no fp32 dpre tensor.  pre / dfeat_main: fp32 or bf16."""
     _chk(pre, pre.dtype); _chk(theta); _chk(sq); _chk(dfeat_main, dfeat_main.dtype)
-    assert pre.dtype in (torch.float32, torch.bfloat16) and dfeat_main.dtype in (torch.float32, torch.bfloat16)
+    assert pre.dtype in (torch.float32, op16()) and dfeat_main.dtype in (torch.float32, op16())
     Bn, L, F = pre.shape
     n = L * F
     sums = torch.empty(3, dtype=torch.float64, device=pre.device)
@@ -684,8 +684,8 @@ def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c,
     dth = torch.empty_like(theta)
     dn = torch.empty(n, dtype=torch.float32, device=pre.device)
     ws = workspace(lib.clt_jumprelu_loss_bf16_workspace_bytes(Bn, n), pre.device)
-    call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), int(pre.dtype == torch.bfloat16), theta.data_ptr(), sq.data_ptr(),
-         dfeat_main.data_ptr(), int(dfeat_main.dtype == torch.bfloat16), float(bandwidth),
+    call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), int(pre.dtype in _DT16), theta.data_ptr(), sq.data_ptr(),
+         dfeat_main.data_ptr(), int(dfeat_main.dtype in _DT16), float(bandwidth),
          float(GRAD_SCALE * lam_over_B), float(c), int(use_tanh), float(GRAD_SCALE * coef_over_BL), dpreT.data_ptr(), db.data_ptr(), dth.data_ptr(),
          dn.data_ptr(), sums.data_ptr(), Bn, n, ws.data_ptr(), ws.numel(), _stream())
     return sums, dpreT, db, dth, dn

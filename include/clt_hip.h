@@ -304,7 +304,8 @@ int clt_select_lists_sharded_f32(int stage_lo, int stage_hi, int world, int rank
  * d_acts) in one pass and the output is written once.  Returns 1 when the shape does not qualify (kseg % 64, alignment). */
 int clt_gemm_bf16_nt_kseg(const uint16_t* A, const uint16_t* const* Bseg, float* C, int M, int N, int nseg, int kseg, long lda,
                           long ldb, long ldc, const float* bias, int accumulate, void* stream);
-/* NT GEMMs whose result leaves as bf16 (C: bf16 [M][N]; ldc, sC in bf16 elements; N % 8 == 0, ldc % 8 == 0): for the dense
+/* NT GEMMs whose result leaves in the 16-bit operand format (bf16; fp16 under clt_set_loss_scaling) (C: [M][N]; ldc, sC in
+ * 16-bit elements; N % 8 == 0, ldc % 8 == 0): for the dense
  * bf16 regime's pre-activations (clt.py:157-165 under bf16 autocast: a bf16 tensor in the reference too) and feature
  * gradients, which are consumed once, elementwise.  Halves the bytes and the store instructions of the K = 768
  * contractions' epilogue, which bounds them.  Fast kernel only: returns 1 when the shape does not qualify. */

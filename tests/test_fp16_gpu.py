@@ -116,7 +116,10 @@ def test_fp16_fused_training_step_scaler_and_skip(dec_kind, nl_kind, loss_kind):
         assert int(st["step"]) == 1, k
         rel_m = float((st["exp_avg"].cpu().reshape(want_m.shape) - want_m).norm() / (want_m.norm() + 1e-30))
         rel_v = float((st["exp_avg_sq"].cpu().reshape(want_v.shape) - want_v).norm() / (want_v.norm() + 1e-30))
-        assert rel_m < 4e-3 and rel_v < 8e-3, f"{k}: exp_avg {rel_m:.3g} exp_avg_sq {rel_v:.3g}"
+        # (theta: its gradient counts the entries inside the rectangle window around theta; with the pre-activations kept as
+        # fp16 — as autocast keeps them — entries at the window's edges switch sides)
+        tol = 1.5e-2 if k == "nonlinearity.theta" else 4e-3
+        assert rel_m < tol and rel_v < 2 * tol, f"{k}: exp_avg {rel_m:.3g} exp_avg_sq {rel_v:.3g}"
         step = (p.detach().cpu() - p0).abs().max()
         assert 0 < float(step) <= 1.01e-3, f"{k}: first Adam step moved by {float(step):.3g}"
     # the 16-bit operand shadows the weight passes refreshed are fp16 copies of the new weights
