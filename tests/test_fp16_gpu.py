@@ -142,3 +142,26 @@ def test_bf16_mode_unaffected_after_fp16():
         ops.sync_operand_format()
         h = ops.cast_bf16(x)
         assert h.dtype == torch.bfloat16 and torch.equal(h, x.bfloat16())
+
+
+def test_debug_yaml_in_16_mixed_follows_the_fp32_curve(tmp_path, golden):
+    """config/debug-cpu.yaml with `trainer.precision: "16-mixed"` (what the reference's production YAMLs set): 100 fused
+    steps from the reference's initial parameters stay on the reference's fp32 loss curve at the 16-bit tolerance (d_acts =
+    110 is not a multiple of 8: the contractions go through the generic fp16 MFMA kernel), the loss scale never backs off."""
+    import os
+    from crosslayer_transcoder_amd import get_precision, set_precision, trainer
+    cur = golden("dbg_yaml_curve")
+    tfile = str(tmp_path / "debug_actvs.pt")
+    torch.save(golden("dbg_jumprelu_clt")["batches"][0], tfile)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = trainer.load_config(os.path.join(root, "config", "debug-cpu.yaml"))
+    cfg["trainer"]["precision"] = "16-mixed"
+    try:
+        mod, losses = trainer.run_config(cfg, tensor_file=tfile, init_state=cur["init_params"], fused=True)
+        assert get_precision() == "fp16" and len(losses) == 100
+        got = torch.stack([x.float().cpu() for x in losses])
+        assert torch.isfinite(got).all()
+        assert_close(got, cur["losses"], 2e-2, 1e-6, "100-step curve in fp16 mode vs the reference's fp32 curve")
+        assert mod.loss_scaler.skipped_steps == 0 and mod.loss_scaler.scale == 65536.0
+    finally:
+        set_precision("32")
