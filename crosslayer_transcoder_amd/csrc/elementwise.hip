@@ -14,19 +14,43 @@ inline int blocks_for(long count, int per_block, int cap = 8192) {
 }
 
 // ---- K1 -------------------------------------------------------------------------------------
-__global__ void column_stats_kernel(const float* __restrict__ x, long rs, int rows, int n, float* __restrict__ mean,
-                                    float* __restrict__ stdv) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)x[(long)r * rs + j];
-    const double mu = s / rows;
-    double q = 0.0;
-    for (int r = 0; r < rows; ++r) { const double dlt = (double)x[(long)r * rs + j] - mu; q += dlt * dlt; }
-    // torch.std: unbiased (N-1); a single row gives nan in torch, as here (0/0)
-    const float sd = (float)sqrt(q / (double)(rows - 1));
-    mean[j] = (float)mu;
-    stdv[j] = sd < 1e-8f ? 1e-8f : sd;    // clamp_(min=1e-8); nan stays nan as in torch.clamp
+// 64 columns x 16 row phases per block: phase p takes rows p, p + 16, ... (4 loads in flight), the 16 partial sums of a
+// column are added in phase order — fp64 throughout, two passes (mean, then squared deviations) as torch.std does
+__global__ __launch_bounds__(1024) void column_stats_kernel(const float* __restrict__ x, long rs, int rows, int n, float* __restrict__ mean,
+                                                            float* __restrict__ stdv) {
+    __shared__ double part[16][64];
+    __shared__ double mu_s[64];
+    const int tx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    const bool in = j < n;
+    auto column_sum = [&](auto f) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (in) {
+            int r = ph;
+            for (; r + 48 < rows; r += 64) {
+                const float a = x[(long)r * rs + j], b = x[(long)(r + 16) * rs + j], c = x[(long)(r + 32) * rs + j], d = x[(long)(r + 48) * rs + j];
+                s0 += f(a); s1 += f(b); s2 += f(c); s3 += f(d);
+            }
+            for (; r < rows; r += 16) s0 += f(x[(long)r * rs + j]);
+        }
+        part[ph][tx] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        double s = 0.0;
+        if (ph == 0) for (int p = 0; p < 16; ++p) s += part[p][tx];
+        __syncthreads();
+        return s;                                    // (valid in phase 0)
+    };
+    const double s = column_sum([](float v) { return (double)v; });
+    if (ph == 0) mu_s[tx] = s / rows;
+    __syncthreads();
+    const double mu = mu_s[tx];
+    const double q = column_sum([mu](float v) { const double dlt = (double)v - mu; return dlt * dlt; });
+    if (ph == 0 && in) {
+        // torch.std: unbiased (N-1); a single row gives nan in torch, as here (0/0)
+        const float sd = (float)sqrt(q / (double)(rows - 1));
+        mean[j] = (float)mu;
+        stdv[j] = sd < 1e-8f ? 1e-8f : sd;    // clamp_(min=1e-8); nan stays nan as in torch.clamp
+    }
 }
 
 template <bool VEC, bool F16>
@@ -834,7 +858,7 @@ int clt_operand_format(void) { return clt_host_state.fp16; }
 
 int clt_column_stats_f32(const float* x, long rs, int rows, int n, float* mean, float* stdv, void* st) {
     if (rows <= 0 || n <= 0 || rs < n) return CLT_ERR_SHAPE;
-    hipLaunchKernelGGL(column_stats_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(st), x, rs, rows, n, mean, stdv);
+    hipLaunchKernelGGL(column_stats_kernel, dim3((n + 63) / 64), dim3(1024), 0, as_stream(st), x, rs, rows, n, mean, stdv);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_standardize_f32(const float* x, long rs, const float* mean, const float* stdv, int rows, int n, float* o32,
