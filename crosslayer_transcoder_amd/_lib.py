@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclt_hip.so")
+if os.environ.get("CLT_HIP_LIBRARY"):           # kernel-variant builds for A/B runs (scripts/build_variants.sh)
+    LIB_PATH = os.environ["CLT_HIP_LIBRARY"]
 
 ERRORS = {-1: "CLT_ERR_SHAPE", -2: "CLT_ERR_K_GT_F", -3: "CLT_ERR_WORKSPACE", -4: "CLT_ERR_ALIGN",
           -5: "CLT_ERR_LAUNCH", -6: "CLT_ERR_RANGE"}
