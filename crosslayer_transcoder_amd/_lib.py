@@ -83,7 +83,7 @@ SIGNATURES = {
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,
                                      P, P, SZ, P]),
-    "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, P]),
+    "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, I, I, P]),
     "clt_sparse_row_pass_group_f32": (I, [I, P, P, P, P, P, P, P, I, I, I, P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_double, I, I, I, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
@@ -96,7 +96,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CltError(RuntimeError):

@@ -28,15 +28,17 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
                                                                  const float* __restrict__ ent_val, const float* const* __restrict__ Wptr,
                                                                  const float* __restrict__ bias, float* __restrict__ out, int L, int F,
                                                                  int d, int cross_layer, uint32_t cap, long out_tok_stride,
-                                                                 long out_layer_stride) {
+                                                                 long out_layer_stride, int l_lo, int l_hi) {
     constexpr int W = VEC ? 4 : 1;
     constexpr int U = NT <= 4 ? 4 : (NT <= 8 ? 2 : 1);         // entries in flight per wave (bounded by the register budget)
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // target layers are dealt to the 4 waves heaviest first in serpentine order (a cross-layer target l gathers the
     // entries of l + 1 source layers): 11,4,3 | 10,5,2 | 9,6,1 | 8,7,0 for L = 12
-    for (int rnd = 0; rnd * 4 < L; ++rnd) {
-        const int l = L - 1 - rnd * 4 - ((rnd & 1) ? 3 - w : w);
-        if (l < 0) continue;
+    // (target layers [l_lo, l_hi): the feature-sharded step launches the forward layer group by layer group, so that a
+    // group's all-reduce runs under the forward of the next)
+    for (int rnd = 0; rnd * 4 < l_hi - l_lo; ++rnd) {
+        const int l = l_hi - 1 - rnd * 4 - ((rnd & 1) ? 3 - w : w);
+        if (l < l_lo) continue;
         const float* Wl = Wptr[l];
         const uint16_t* Wh = reinterpret_cast<const uint16_t*>(Wl);   // BF: the table points at bf16 shadow rows
         const int lo = cross_layer ? 0 : l;
@@ -426,19 +428,21 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,
                                const float* bias, float* out, int B, int L, int F, int d, int cross_layer, uint32_t cap,
-                               int w_bf16, long out_tok_stride, long out_layer_stride, void* stp) {
+                               int w_bf16, long out_tok_stride, long out_layer_stride, int layer_lo, int layer_hi, void* stp) {
     if (B <= 0 || L <= 0 || F <= 0 || d <= 0) return CLT_ERR_SHAPE;
+    if (layer_lo == 0 && layer_hi == 0) layer_hi = L;
+    if (layer_lo < 0 || layer_hi > L || layer_lo >= layer_hi) return CLT_ERR_SHAPE;
     if (out_tok_stride == 0 && out_layer_stride == 0) { out_tok_stride = (long)L * d; out_layer_stride = d; }   // [B][L][d]
     const bool vec = d % 4 == 0 && aligned16(out) && out_tok_stride % 4 == 0 && out_layer_stride % 4 == 0;
 #define FWDK(NT_, VEC_)                                                                                              \
     do {                                                                                                              \
         if (w_bf16 && clt_host_state.fp16)                                                                            \
             hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true, true>), dim3(B), dim3(TPB), 0, as_stream(stp), \
-                               row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
+                               row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride, layer_lo, layer_hi); \
         else if (w_bf16) hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, true>), dim3(B), dim3(TPB), 0, as_stream(stp),  \
-                                       row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
+                                       row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride, layer_lo, layer_hi); \
         else hipLaunchKernelGGL((sparse_decoder_fwd_kernel<NT_, VEC_, false>), dim3(B), dim3(TPB), 0, as_stream(stp), \
-                                row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride); \
+                                row_start, ent_col, ent_val, Wptr, bias, out, L, F, d, cross_layer, cap, out_tok_stride, out_layer_stride, layer_lo, layer_hi); \
     } while (0)
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);
     if (vec) {

@@ -441,6 +441,18 @@ def _threshold_lists(mod, pre, theta, force: bool):
     return S
 
 
+def _forward_and_exchange(D, S, shard, d):
+    """Pipelined exchange, forward half: the partial reconstruction layer-major [L, B, d], gathered layer group by layer
+    group (last layers first); each group's all-reduce is queued on RCCL's stream as soon as its slabs are written, so it
+    runs under the gather of the next group (and later under the weight passes).  Returns (r_lm, [wait per group])."""
+    r_lm, waits = None, []
+    for lo, hi in _exchange_groups(D.L):
+        r_lm = ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True, w_bf16=D.shadow, layer_major=True, out=r_lm,
+                                      layers=(lo, hi))
+        waits.append(shard.all_reduce_sum_async(r_lm[lo:hi]))
+    return r_lm, waits
+
+
 def _exchange_groups(L):
     """Layer groups of the pipelined exchange, last layers first, as (lo, hi) ranges: sizes 1, 2, 3, rest — the first group
     is small (its all-reduce is the only one nothing can hide) and every later group's all-reduce runs under the weight
@@ -556,7 +568,9 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         def _spec_fwd(S_):
             D_ = _Decoder(dec, shard, shadow=optimizer is not None)
             lm = bool(PIPELINE_EXCHANGE and shard is not None and D_.clt and not fp16)
-            return D_, lm, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow, layer_major=lm)
+            if lm:
+                return (D_, True) + _forward_and_exchange(D_, S_, shard, d)
+            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None
 
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
                                           nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
@@ -643,6 +657,11 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     def dead_features():
         dd, cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
         if shard is not None:                 # features are split over ranks: count over all shards
+            if pipelined:
+                # (queued behind the layer groups' all-reduces on RCCL's stream: nobody waits for it before the end of the
+                # step — a blocking all-reduce here would hold the weight passes until the whole exchange had finished)
+                cnt = cnt.clone()
+                return dd, (cnt, shard.all_reduce_sum_async(cnt))
             cnt = shard.all_reduce_sum(cnt.clone())
         return dd, cnt
 
@@ -650,12 +669,10 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         # partial reconstruction layer-major [L, B, d].  Launched first (the host has just read the selection's outcome flag
         # and the launch queue is empty); the dead-feature update and its tiny all-reduce follow, and only then are the
         # all-reduces of the layer groups queued on RCCL's stream — no small collective waits behind them
-        r_lm = spec[2] if spec is not None and spec[1] else ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True,
-                                                                                   w_bf16=D.shadow, layer_major=True)
+        groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
+        r_lm, waits = (spec[2], spec[3]) if spec is not None and spec[1] else _forward_and_exchange(D, S, shard, d)
         if pending is None:
             dead, dead_cnt = dead_features()
-        groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
-        waits = [shard.all_reduce_sum_async(r_lm[lo:hi]) for lo, hi in groups]
         r = None
     else:
         if sparse:
@@ -707,7 +724,11 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     if pending is not None:
         pending()                                        # raises _VoidAttempt when the fused selection did not hold
         dead, dead_cnt = dead_features()
-    terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
+    if isinstance(dead_cnt, tuple):                      # pipelined exchange: the count's all-reduce is waited for at the end
+        late_dead, dead_cnt = dead_cnt, None
+    else:
+        late_dead = None
+        terms["dead_fraction"] = dead_cnt[0].float() / (L * F * (shard.world if shard is not None else 1))
     out = StepOutput(terms=terms, grads=grads, dead=dead)
     out["grad_scale"] = ops.GRAD_SCALE           # out["grads"] carry this factor (1.0 outside fp16 mode)
     out.lazy = {}
@@ -788,6 +809,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         if pipelined:
             terms["mse"] = (loss_parts.sum() / N).float()
             loss = terms["mse"]
+            late_dead[1]()
+            terms["dead_fraction"] = late_dead[0][0].float() / (L * F * shard.world)
         # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
         # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
         db = torch.empty(L, F, dtype=torch.float32, device=dev)

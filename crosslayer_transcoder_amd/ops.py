@@ -1104,14 +1104,17 @@ def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
 
 
 def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool,
-                       w_bf16: bool = False, layer_major: bool = False):
+                       w_bf16: bool = False, layer_major: bool = False, out: Optional[torch.Tensor] = None, layers=None):
     """wptr: device table of per-target-layer weight pointers (fp32 rows, or bf16 shadow rows when w_bf16).
-    layer_major: the result as [L, B, d] (every layer's slab contiguous) instead of [B, L, d]."""
-    out = torch.empty((s.L, s.B, d) if layer_major else (s.B, s.L, d), dtype=torch.float32, device=wptr.device)
+    layer_major: the result as [L, B, d] (every layer's slab contiguous) instead of [B, L, d].
+    out / layers = (lo, hi): write only the target layers [lo, hi) of a result tensor allocated earlier."""
+    if out is None:
+        out = torch.empty((s.L, s.B, d) if layer_major else (s.B, s.L, d), dtype=torch.float32, device=wptr.device)
     ts, ls = (d, s.B * d) if layer_major else (s.L * d, d)
+    lo, hi = layers if layers is not None else (0, s.L)
     call("clt_sparse_decoder_fwd_f32", s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(),
          wptr.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), s.B, s.L, s.F, d,
-         int(cross_layer), s.cap, int(w_bf16), ts, ls, _stream())
+         int(cross_layer), s.cap, int(w_bf16), ts, ls, lo, hi, _stream())
     return out
 
 

@@ -358,11 +358,12 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
  * Wptr: DEVICE array of L device pointers (to fp32 rows, or — w_bf16 != 0 — to the bf16 shadow copies that the
  * Adam row pass maintains: half the gathered bytes in bf16 mode).  out[b,l,:] starts at out + b*out_tok_stride +
  * l*out_layer_stride (elements; both 0 = the contiguous [B][L][d] layout): the feature-sharded step writes the partial
- * reconstruction layer-major ([L][B][d]) so that every layer's slab is one contiguous all-reduce. */
+ * reconstruction layer-major ([L][B][d]) so that every layer's slab is one contiguous all-reduce.  Only the target layers
+ * [layer_lo, layer_hi) are computed (0, 0 = all): that step launches the forward layer group by layer group. */
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val,
                                const float* const* Wptr, const float* bias, float* out, int B, int L, int F, int d,
                                int cross_layer, uint32_t cap, int w_bf16, long out_tok_stride, long out_layer_stride,
-                               void* stream);
+                               int layer_lo, int layer_hi, void* stream);
 /* One streaming pass over `rows` weight rows W[r][0:d] (row r <-> CSC column col0 + r):
  *   grad[r,:]  = sum_{p in column} coef[p] * src[tok[p], layer, :]   (+ the same over the optional 2nd list)
  *   dot_out[slot*dot_stride + p] = src[tok[p], layer, :] . W[r,:]    (pre-update weights; dot_out2: the same for

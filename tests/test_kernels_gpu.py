@@ -679,3 +679,21 @@ def test_gemm_nt_bf16_output(ops, Bn, L, d, F):
         Ws = [ops.cast_bf16((torch.randn(l + 1, F, d, generator=g) * 0.1).cuda()) for l in range(L)]
         d32, d16 = ops.clt_decoder_dgrad_kseg(gg, Ws), ops.clt_decoder_dgrad_kseg(gg, Ws, True)
         assert d32 is not None and d16 is not None and torch.equal(d16, d32.bfloat16())
+
+
+def test_sparse_decoder_fwd_layer_ranges(ops):
+    """The gather forward restricted to target-layer ranges (what the feature-sharded step launches group by group) fills
+    the same result as one launch over all layers, in both output layouts."""
+    B, L, F, d = 19, 7, 64, 48
+    feat = _sparse_features(B, L, F, 5, seed=9)
+    S = ops.sparse_build(feat.to(DEV), 5 * B * L)
+    Wd = [_rand(l + 1, F, d, seed=50 + l, scale=0.05).to(DEV) for l in range(L)]
+    wptr = ops.pointer_table(Wd)
+    bias = _rand(L, d, seed=8, scale=0.1).to(DEV)
+    for lm in (False, True):
+        full = ops.sparse_decoder_fwd(S, wptr, bias, d, True, layer_major=lm)
+        out = None
+        for lo, hi in ((6, 7), (4, 6), (1, 4), (0, 1)):
+            out = ops.sparse_decoder_fwd(S, wptr, bias, d, True, layer_major=lm, out=out if out is not None else torch.full_like(full, float("nan")),
+                                         layers=(lo, hi))
+        assert torch.equal(out, full)
