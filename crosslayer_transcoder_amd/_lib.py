@@ -39,6 +39,8 @@ SIGNATURES = {
     "clt_topk_segmented_workspace_bytes": (SZ, [I, I, I, I]),
     "clt_topk_segmented_f32": (I, [P, P, I, I, I, I, I, P, F32, P, SZ, P]),
     "clt_mask_positive_f32": (I, [P, P, P, L, I, P]),
+    "clt_mask_positive_t_workspace_bytes": (SZ, [I, I]),
+    "clt_mask_positive_t_f32": (I, [P, P, I, I, P, P, P, SZ, P]),
     "clt_threshold_fwd_f32": (I, [P, P, I, P, I, I, I, P]),
     "clt_mask_dead_f32": (I, [P, P, P, I, I, P]),
     "clt_reduce_workspace_bytes": (SZ, [L]),
@@ -96,7 +98,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CltError(RuntimeError):

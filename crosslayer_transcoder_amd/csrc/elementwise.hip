@@ -720,6 +720,58 @@ __global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __r
     s = block_sum_d(s_w, sh); if (threadIdx.x == 0) part_s[b * 3 + 2] = s;
 }
 
+// Backward of a selection's relu + scatter (topk.py:61-65: the gradient reaches the kept, positive entries only) for the dense
+// compacted TopK-aux pass in the 16-bit modes: dpre = feat > 0 ? dfeat : 0, written ONCE as the transposed 16-bit operand
+// [n][rows] of the encoder weight-gradient GEMM, with its column sums (the encoder bias gradient) — instead of a masked fp32
+// tensor, a transposing cast of it and a column-sum pass over it.  grid (ceil(n/256), ceil(rows/256)); part: [gridDim.y][n].
+template <bool F16>
+__global__ __launch_bounds__(256) void mask_positive_t_kernel(const float* __restrict__ feat, const float* __restrict__ dfeat, int rows,
+                                                              int n, uint16_t* __restrict__ dpreT, float* __restrict__ part) {
+    __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
+    float (*red)[FT_C] = reinterpret_cast<float (*)[FT_C]>(&tile[0][0]);      // [4][256] floats: reuses the tile after the loop
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long c0 = (long)blockIdx.x * FT_C;
+    const long col = c0 + 4 * tx;
+    const bool cin = col < n;
+    float a_db[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r0 = (blockIdx.y * 4 + rt) * FT_R;
+        if (r0 >= rows) break;
+        for (int i0 = 0; i0 < 8; i0 += 2) {                  // two row pairs (four rows) loaded ahead of their arithmetic
+            float4 v4[4], g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
+                v4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); g4[u] = v4[u];
+                if (cin && row < rows) {
+                    v4[u] = *reinterpret_cast<const float4*>(feat + (long)row * n + col);
+                    g4[u] = *reinterpret_cast<const float4*>(dfeat + (long)row * n + col);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float dpv[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v[4] = {v4[2 * u + e].x, v4[2 * u + e].y, v4[2 * u + e].z, v4[2 * u + e].w};
+                    const float gg[4] = {g4[2 * u + e].x, g4[2 * u + e].y, g4[2 * u + e].z, g4[2 * u + e].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float dp = v[k] > 0.0f ? gg[k] : 0.0f; a_db[k] += dp; dpv[e][k] = dp; }
+                }
+                ft_store_pair<F16>(tile, w + 4 * (i0 + u), tx, dpv[0], dpv[1]);
+            }
+        }
+        __syncthreads();
+        ft_write_transposed(tile, dpreT, c0, r0, rows, n);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[w][4 * tx + k] = a_db[k];
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (c0 + j < n) part[(long)blockIdx.y * n + c0 + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+}
+
 // ---- logging side outputs (clt_lightning.py:131-199): per-column sums over the batch, fp64 ----------------------
 // out[j][0..5] = sum_r (yn - r)^2, sum yn, sum yn^2, sum (r*std + mean - y)^2, sum r, sum r^2   (yn = (y - mean)/std)
 __global__ __launch_bounds__(256) void recon_metrics_kernel(const float* __restrict__ r, const float* __restrict__ y, long yrs,
@@ -841,7 +893,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 6; }
+int clt_abi_version(void) { return 7; }
 
 int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
     if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;
@@ -1088,6 +1140,20 @@ int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, co
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)part, gy, n, dtheta, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)gy * n), gy, n, dnorm, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)2 * gy * n), gy, n, dbias, 0);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+size_t clt_mask_positive_t_workspace_bytes(int rows, int n) {
+    return (size_t)((rows + 4 * FT_R - 1) / (4 * FT_R)) * (size_t)n * sizeof(float);
+}
+int clt_mask_positive_t_f32(const float* feat, const float* dfeat, int rows, int n, uint16_t* dpreT, float* colsum, void* ws, size_t wsb,
+                            void* st) {
+    if (rows <= 0 || n <= 0 || !feat || !dfeat || !dpreT || !colsum) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(feat) || !aligned16(dfeat) || !aligned16(dpreT)) return CLT_ERR_ALIGN;
+    if (!ws || wsb < clt_mask_positive_t_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
+    const int gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C, gc = (n + TPB - 1) / TPB;
+    if (clt_host_state.fp16) hipLaunchKernelGGL((mask_positive_t_kernel<true>), dim3(gx, gy), dim3(256), 0, as_stream(st), feat, dfeat, rows, n, dpreT, (float*)ws);
+    else hipLaunchKernelGGL((mask_positive_t_kernel<false>), dim3(gx, gy), dim3(256), 0, as_stream(st), feat, dfeat, rows, n, dpreT, (float*)ws);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)ws, gy, n, colsum, 0);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_recon_metrics_f32(const float* r, const float* y, long yrs, const float* mean, const float* stdv, int rows, int n,

@@ -114,6 +114,8 @@ def _side_stream(dev):
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
 COMPACT_AUX_MAX_SHARE = 0.5
+COMPACT_AUX_FUSED_OPERANDS = os.environ.get("CLT_AUX_FUSED_OPS", "1") != "0"     # (0: separate cast / transpose / mask passes)
+COMPACT_AUX_GEMM_COLUMNS = os.environ.get("CLT_AUX_GEMM_COLS", "1") != "0"       # (0: gather them from `pre`, for A/B runs)
 #: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
 #: dense bf16 JumpReLU regime: pre-activations / feature gradient stored as bf16 (CLT_DENSE_BF16_ACT=0: fp32, for A/B runs)
@@ -769,14 +771,22 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             if cx is not None:
                 # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
                 n_pad, cidx, cmap = cx
-                pre_c = ops.gather_cols(pre, cidx, float("-inf"))
+                # (16-bit modes: the dead columns' pre-activations come from the encoder GEMM on the gathered weight rows — same
+                # kernel, same bits — instead of a second read of `pre`: every 64-byte line of it holds a dead column or two)
+                if bf16 and F % 4 == 0 and d % 8 == 0 and Bn * n_pad >= 256 * 256 and COMPACT_AUX_GEMM_COLUMNS:
+                    pre_c = ops.encoder_fwd_columns(xo, enc.Wt, enc.b, cidx)
+                else:
+                    pre_c = ops.gather_cols(pre, cidx, float("-inf"))
                 if shard is None:
                     feat_c = ops.topk_rows(pre_c, min(aux.k, n_pad))
                 else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
                     Sc = ops.select_rows_sharded(pre_c, aux.k, shard, local_columns=True)
                     feat_c = ops.sparse_scatter_dense(Sc, Sc.csc_val)
                 Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
-                aux_r = Dc.fwd(feat_c)
+                # 16-bit modes: both GEMM operand forms of the compact features (row-major for the forward, transposed for the
+                # weight gradient) from ONE read of them (the ReLU tile pass of the dense regime: feat_c >= 0 already)
+                fc16 = ops.jumprelu_fwd_bf16(feat_c, None)[:2] if (bf16 and COMPACT_AUX_FUSED_OPERANDS and Bn % 8 == 0) else None
+                aux_r = Dc.fwd(feat_c, feat_op=fc16[0] if fc16 is not None else None)
             else:
                 S2 = _select_lists(aux, pre, dead, shard)
                 aux_r = D.sparse_fwd(S2)
@@ -794,16 +804,21 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         extra_dec = extra_enc = None
         if cx is not None:
             gc: Dict[str, torch.Tensor] = {}
-            Dc.wgrad(feat_c, g_aux, gc)
-            dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
+            Dc.wgrad(feat_c, g_aux, gc, featT=fc16[1] if fc16 is not None else None)
+            if fc16 is not None:
+                # masked feature gradient straight to the transposed 16-bit operand + its column sums (no fp32 dpre tensor)
+                dT_c, db_c = ops.mask_positive_t(feat_c, Dc.dgrad(g_aux))
+            else:
+                dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
+                dT_c = ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn) if bf16 else None
+                db_c = ops.column_sum(dpre_c)
             if bf16:
                 dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=dev)
-                ops.wgrad_t(ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn), ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L,
-                            n_pad * Bn, d * Bn)
+                ops.wgrad_t(dT_c, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L, n_pad * Bn, d * Bn)
             else:
                 dWt_c = ops.encoder_wgrad(xs32, dpre_c)
             extra_dec = (gc, cmap)
-            extra_enc = (dWt_c.view(-1, d), cmap, ops.column_sum(dpre_c).view(-1))
+            extra_enc = (dWt_c.view(-1, d), cmap, db_c.view(-1))
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
                                    slabs=slabs, groups=groups if pipelined else None)
         if pipelined:

@@ -528,6 +528,19 @@ def mask_positive(feat, g, out=None, accumulate=False):
     return dx
 
 
+def mask_positive_t(feat: torch.Tensor, dfeat: torch.Tensor):
+    """dpre = feat > 0 ? dfeat : 0 as the transposed 16-bit GEMM operand + its column sums, one pass (clt_mask_positive_t_f32).
+    feat / dfeat: fp32 [B, L, n] -> (dpreT 16-bit [L, n, B], colsum fp32 [L, n])."""
+    _chk(feat); _chk(dfeat)
+    Bn, L, n = feat.shape
+    dpreT = torch.empty(L, n, Bn, dtype=op16(), device=feat.device)
+    cs = torch.empty(L, n, dtype=torch.float32, device=feat.device)
+    ws = workspace(lib.clt_mask_positive_t_workspace_bytes(Bn, L * n), feat.device)
+    call("clt_mask_positive_t_f32", feat.data_ptr(), dfeat.data_ptr(), Bn, L * n, dpreT.data_ptr(), cs.data_ptr(), ws.data_ptr(),
+         ws.numel(), _stream())
+    return dpreT, cs
+
+
 def threshold_fwd(x, threshold, per_layer: bool, L: int):
     """Inference path; x: [..., F] of one layer or [B, L, F]."""
     _chk(x); _chk(threshold)
@@ -1215,6 +1228,21 @@ def gather_cols(x: torch.Tensor, idx: torch.Tensor, fill: float) -> torch.Tensor
     out = torch.empty(Bn, L, n_pad, dtype=torch.float32, device=x.device)
     call("clt_gather_cols_f32", x.data_ptr(), idx.data_ptr(), Bn * L, L, F, n_pad, float(fill), out.data_ptr(), _stream())
     return out
+
+
+def encoder_fwd_columns(xs: torch.Tensor, Wt32: torch.Tensor, b: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """gather_cols(encoder_fwd(xs, Wt, b), idx, -inf) without reading the [B, L, F] pre-activations again: the encoder GEMM
+    on the gathered weight rows (xs 16-bit [B, L, d]; Wt32 fp32 [L, F, d]; idx int32 [L, n_pad], -1 = pad).  Every output
+    element of the NT kernel accumulates over k in an order that does not depend on its place in the tile grid, so the values
+    are bit-identical to the full GEMM's as long as both launches take the same kernel (the caller checks the shape
+    conditions that decide that); a pad column is 0 * x + (-inf).  The compacted TopK-aux pass: 1.5 -> 0.55 ms at 14 % dead."""
+    L, F, d = Wt32.shape
+    n_pad = idx.shape[1]
+    Wc = gather_rows(Wt32, idx)                                  # zero rows at the pads
+    if xs.dtype in _DT16:
+        Wc = cast_bf16(Wc)
+    bc = gather_cols(b.reshape(1, L, F), idx, float("-inf")).view(L, n_pad)
+    return encoder_fwd(xs, Wc, bc)
 
 
 def gather_rows(W: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -109,6 +109,13 @@ int clt_topk_segmented_f32(const float* x, float* feat_out, int B, int L, int F,
 /* backward of scatter(relu(gather)): dx (+)= g * [feat > 0]. */
 int clt_mask_positive_f32(const float* feat, const float* g, float* dx, long count, int accumulate,
                           void* stream);
+/* The same backward for the dense compacted TopK-aux pass in the 16-bit modes (clt_lightning.py:539-553 under autocast):
+ * dpre = feat > 0 ? dfeat : 0 written once as the TRANSPOSED 16-bit operand dpreT [n][rows] of the encoder weight-gradient
+ * GEMM (the transposes autograd makes for that bmm), plus colsum[n] = its column sums (the encoder bias gradient).
+ * feat / dfeat: fp32 [rows][n]; rows % 8 == 0, n % 4 == 0. */
+size_t clt_mask_positive_t_workspace_bytes(int rows, int n);
+int clt_mask_positive_t_f32(const float* feat, const float* dfeat, int rows, int n, uint16_t* dpreT, float* colsum,
+                            void* workspace, size_t ws_bytes, void* stream);
 /* inference path (topk.py:71-74, 104-107): out = x > max(thr[seg],0) ? x : 0, seg = 0 or layer. */
 int clt_threshold_fwd_f32(const float* x, const float* threshold, int per_layer, float* out, int B, int L,
                           int F, void* stream);

@@ -697,3 +697,38 @@ def test_sparse_decoder_fwd_layer_ranges(ops):
             out = ops.sparse_decoder_fwd(S, wptr, bias, d, True, layer_major=lm, out=out if out is not None else torch.full_like(full, float("nan")),
                                          layers=(lo, hi))
         assert torch.equal(out, full)
+
+
+@pytest.mark.parametrize("Bn,L,d,F,share", [(1024, 3, 768, 8192, 0.14), (4096, 2, 256, 32768, 0.1), (512, 2, 128, 1028, 0.4)])
+def test_encoder_fwd_columns_is_gather_of_full_gemm(ops, Bn, L, d, F, share):
+    """The compacted TopK-aux pass takes the dead columns' pre-activations from the encoder GEMM on the gathered weight rows:
+    bit for bit the columns of the full GEMM (same kernel, k order independent of the tile), -inf at the pad columns."""
+    g = torch.Generator().manual_seed(Bn + F)
+    xs = ops.cast_bf16(torch.randn(Bn, L, d, generator=g).cuda())
+    Wt32 = (torch.randn(L, F, d, generator=g) * 0.05).cuda()
+    b = (torch.randn(L, F, generator=g) * 0.1).cuda()
+    dead = (torch.rand(L, F, generator=g) < share).to(torch.uint8).cuda()
+    dead[1] = 0
+    dead[1, ::7] = 1                                             # (layers with different counts: pad columns)
+    n_pad, cidx, _ = ops.compact_columns(dead)
+    assert Bn * n_pad >= 256 * 256
+    pre = ops.encoder_fwd(xs, ops.cast_bf16(Wt32), b)
+    ref = ops.gather_cols(pre, cidx, float("-inf"))
+    got = ops.encoder_fwd_columns(xs, Wt32, b, cidx)
+    assert torch.isinf(ref).any() and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("Bn,L,n", [(256, 2, 512), (72, 3, 132), (1000, 1, 260)])
+def test_mask_positive_transposed_one_pass(ops, Bn, L, n):
+    """clt_mask_positive_t_f32 = mask_positive, then the transposing 16-bit cast, then column sums — in one pass: the operand
+    bit for bit, the column sums to fp32 summation-order tolerance."""
+    g = torch.Generator().manual_seed(Bn + n)
+    feat = torch.relu(torch.randn(Bn, L, n, generator=g) - 0.8).cuda()
+    dfeat = torch.randn(Bn, L, n, generator=g).cuda()
+    dpre = ops.mask_positive(feat, dfeat)
+    refT = ops.transpose_cast_2d(dpre).view(L, n, Bn)
+    refc = ops.column_sum(dpre)
+    gotT, gotc = ops.mask_positive_t(feat, dfeat)
+    assert torch.equal(gotT.view(torch.int16), refT.view(torch.int16))
+    assert_close(gotc.cpu(), dpre.cpu().double().sum(0).float(), **tol(refc.cpu()))
+    assert_close(gotc.cpu(), refc.cpu(), **tol(refc.cpu()))
