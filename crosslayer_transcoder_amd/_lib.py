@@ -30,6 +30,7 @@ SIGNATURES = {
     "clt_cast_bf16": (I, [P, P, L, P]),
     "clt_cast_transpose_bf16": (I, [P, L, P, L, I, I, I, L, L, P]),
     "clt_weight_prep_bf16": (I, [P, I, I, I, P, P, P, I, P]),
+    "clt_weight_prep_gather_bf16": (I, [P, P, I, I, I, I, P, P, P]),
     "clt_relu_fwd_f32": (I, [P, P, L, P]),
     "clt_relu_bwd_f32": (I, [P, P, P, L, P]),
     "clt_jumprelu_fwd_f32": (I, [P, P, P, I, I, P]),

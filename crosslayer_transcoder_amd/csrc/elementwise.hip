@@ -564,19 +564,29 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 // squared row norms sq[b*rows + r] (+)= sum_j W^2 (dec_norms of the sparsity penalty, clt_lightning.py:438-448) — three
 // separate passes over 7.85 GB of decoder weights otherwise.  grid (ceil(rows/64), nb); a block walks the column tiles of
 // its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
-template <bool F16>
+// GATHER: output row r of group g is input row ridx[g * rows + r] of the group's src_rows input rows (< 0: a zero row) — the
+// compacted TopK-aux pass preps the dead rows of the decoder matrices without a gathered fp32 copy in between.
+template <bool F16, bool GATHER = false>
 __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
-                                                          uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate) {
+                                                          uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate,
+                                                          const int32_t* __restrict__ ridx = nullptr, int src_rows = 0) {
     __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
     const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r0 = blockIdx.x * FT_R;
     const long boff = (long)blockIdx.y * rows * n;
-    W += boff;
+    W += GATHER ? (long)blockIdx.y * src_rows * n : boff;
     if (op) op += boff;
     if (opT) opT += boff;
     float acc[16];
+    int srow[GATHER ? 16 : 1];                                  // GATHER: input row of each of this thread's 16 output rows (-1: none)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int i = 0; i < 16; ++i) {
+        acc[i] = 0.0f;
+        if (GATHER) {
+            const int row = r0 + 2 * (w + 4 * (i >> 1)) + (i & 1);
+            srow[i] = row < rows ? ridx[(long)blockIdx.y * rows + row] : -1;
+        }
+    }
     for (long c0 = 0; c0 < n; c0 += FT_C) {
         const long col = c0 + 4 * tx;
         const bool cin = col < n;
@@ -586,9 +596,10 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
             float f[2][4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const bool in = cin && row + e < rows;
+                const long sr = GATHER ? (long)srow[GATHER ? 2 * i + e : 0] : (long)(row + e);
+                const bool in = cin && (GATHER ? sr >= 0 : row + e < rows);
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (in) v = *reinterpret_cast<const float4*>(W + (long)(row + e) * n + col);
+                if (in) v = *reinterpret_cast<const float4*>(W + sr * n + col);
                 acc[2 * i + e] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 f[e][0] = v.x; f[e][1] = v.y; f[e][2] = v.z; f[e][3] = v.w;
             }
@@ -1203,8 +1214,19 @@ int clt_cast_bf16(const float* in, uint16_t* out, long n, void* st) {
 int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, uint16_t* opT, float* sq, int accumulate, void* st) {
     if (nb <= 0 || rows <= 0 || n <= 0 || !W) return CLT_ERR_SHAPE;
     if (rows % 8 || n % 4 || !aligned16(W) || (op && !aligned16(op)) || (opT && !aligned16(opT))) return CLT_ERR_ALIGN;
-    if (clt_host_state.fp16) hipLaunchKernelGGL((weight_prep_kernel<true>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
-    else hipLaunchKernelGGL((weight_prep_kernel<false>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate);
+    if (clt_host_state.fp16) hipLaunchKernelGGL((weight_prep_kernel<true>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate, (const int32_t*)nullptr, 0);
+    else hipLaunchKernelGGL((weight_prep_kernel<false>), dim3((rows + FT_R - 1) / FT_R, nb), dim3(256), 0, as_stream(st), W, rows, n, op, opT, sq, accumulate, (const int32_t*)nullptr, 0);
+    CLT_LAUNCH_CHECK();
+    return CLT_OK;
+}
+
+int clt_weight_prep_gather_bf16(const float* W, const int32_t* ridx, int nb, int src_rows, int rows, int n, uint16_t* op, uint16_t* opT,
+                                void* st) {
+    if (nb <= 0 || rows <= 0 || src_rows <= 0 || n <= 0 || !W || !ridx) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(W) || (op && !aligned16(op)) || (opT && !aligned16(opT))) return CLT_ERR_ALIGN;
+    const dim3 grid((rows + FT_R - 1) / FT_R, nb);
+    if (clt_host_state.fp16) hipLaunchKernelGGL((weight_prep_kernel<true, true>), grid, dim3(256), 0, as_stream(st), W, rows, n, op, opT, (float*)nullptr, 0, ridx, src_rows);
+    else hipLaunchKernelGGL((weight_prep_kernel<false, true>), grid, dim3(256), 0, as_stream(st), W, rows, n, op, opT, (float*)nullptr, 0, ridx, src_rows);
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -782,7 +782,13 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
                     Sc = ops.select_rows_sharded(pre_c, aux.k, shard, local_columns=True)
                     feat_c = ops.sparse_scatter_dense(Sc, Sc.csc_val)
-                Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
+                if bf16 and COMPACT_AUX_FUSED_OPERANDS and d % 4 == 0 and all(w.is_contiguous() for w in D.W32):
+                    # 16-bit operand forms of the dead rows straight from the decoder matrices (no gathered fp32 copies)
+                    Dc = _Decoder(_CompactDecoder(dec, [None] * len(D.W32), n_pad), shard, clt=D.clt)
+                    prepped = [ops.weight_prep_gather_bf16(w, cidx) for w in D.W32]
+                    Dc._Wop, Dc._WT = [p[0] for p in prepped], [p[1] for p in prepped]
+                else:
+                    Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
                 # 16-bit modes: both GEMM operand forms of the compact features (row-major for the forward, transposed for the
                 # weight gradient) from ONE read of them (the ReLU tile pass of the dense regime: feat_c >= 0 already)
                 fc16 = ops.jumprelu_fwd_bf16(feat_c, None)[:2] if (bf16 and COMPACT_AUX_FUSED_OPERANDS and Bn % 8 == 0) else None

@@ -459,6 +459,19 @@ def weight_prep_bf16(w: torch.Tensor, sq: Optional[torch.Tensor] = None, accumul
     return op, opT
 
 
+def weight_prep_gather_bf16(w: torch.Tensor, idx: torch.Tensor):
+    """weight_prep_bf16(gather_rows(w, idx)) without the gathered fp32 copy: w fp32 [groups, F, n]; idx int32 [>= groups, n_pad]
+    (group g uses row g; -1 = zero row) -> (16-bit [groups, n_pad, n], 16-bit [groups, n, n_pad])."""
+    _chk(w); _chk(idx, torch.int32)
+    groups, F, n = w.shape
+    n_pad = idx.shape[1]
+    assert idx.shape[0] >= groups and n_pad % 8 == 0 and n % 4 == 0
+    op = torch.empty(groups, n_pad, n, dtype=op16(), device=w.device)
+    opT = torch.empty(groups, n, n_pad, dtype=op16(), device=w.device)
+    call("clt_weight_prep_gather_bf16", w.data_ptr(), idx.data_ptr(), groups, F, n_pad, n, op.data_ptr(), opT.data_ptr(), _stream())
+    return op, opT
+
+
 # ----------------------------------------------------------------------------------------------- K3
 def relu_fwd(x):
     out = torch.empty_like(_chk(x))

@@ -77,6 +77,11 @@ int clt_cast_transpose_bf16(const float* in, long ld_in, uint16_t* out, long ld_
  * clt_lightning.py:438-448).  op / opT / sq may each be NULL. */
 int clt_weight_prep_bf16(const float* W, int nb, int rows, int n, uint16_t* op, uint16_t* opT, float* sq, int accumulate,
                          void* stream);
+/* The same pass reading its rows through an index: output row r of group g = input row ridx[g*rows + r] of that group's
+ * src_rows input rows (W: [nb][src_rows][n]; ridx < 0: a zero row).  The compacted TopK-aux pass (clt_lightning.py:539-553)
+ * preps the dead rows of every decoder matrix without a gathered fp32 copy. */
+int clt_weight_prep_gather_bf16(const float* W, const int32_t* ridx, int nb, int src_rows, int rows, int n, uint16_t* op,
+                                uint16_t* opT, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  ReLU / JumpReLU — model/jumprelu.py:17-22, :31-48

@@ -732,3 +732,17 @@ def test_mask_positive_transposed_one_pass(ops, Bn, L, n):
     assert torch.equal(gotT.view(torch.int16), refT.view(torch.int16))
     assert_close(gotc.cpu(), dpre.cpu().double().sum(0).float(), **tol(refc.cpu()))
     assert_close(gotc.cpu(), refc.cpu(), **tol(refc.cpu()))
+
+
+def test_weight_prep_gather_equals_prep_of_gathered_rows(ops):
+    """clt_weight_prep_gather_bf16: both 16-bit operand forms of the indexed rows, bit for bit what weight_prep_bf16 makes of
+    gather_rows' fp32 copy (zero rows at the pads)."""
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(3, 500, 132, generator=g).cuda()
+    dead = (torch.rand(4, 500, generator=g) < 0.3).to(torch.uint8).cuda()
+    dead[2, 100:] = 0
+    n_pad, cidx, _ = ops.compact_columns(dead)
+    ref_op, ref_T = ops.weight_prep_bf16(ops.gather_rows(w, cidx))
+    op, opT = ops.weight_prep_gather_bf16(w, cidx)
+    assert (cidx < 0).any()
+    assert torch.equal(op.view(torch.int16), ref_op.view(torch.int16)) and torch.equal(opT.view(torch.int16), ref_T.view(torch.int16))
