@@ -520,14 +520,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
     return v;
 }
-template <int J>                                       // float4 groups per lane: F <= 256 * J
-__global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
+// (LIST: list output compiled in.  The register budget is set for 3-4 waves per SIMD — left to itself the compiler spends 270
+// registers on the fully unrolled row and one wave per SIMD then waits out every cross-lane reduction on its own)
+template <int J, bool LIST>                            // float4 groups per lane: F <= 256 * J
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(J >= 24 ? 3 : 4)))
+void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat, int F, int k,
                                                              int32_t* __restrict__ idx_out, float* __restrict__ val_out,
                                                              const uint8_t* __restrict__ col_mask, int L,
                                                              uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ col_cnt, long nrows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;                          // (whole waves leave; nothing below synchronises the block)
+    if (!LIST) idx_out = nullptr;
     const float* xr = x + row * F;
     const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
     uint32_t key[J * 4];
@@ -545,13 +549,63 @@ __global__ __launch_bounds__(256) void topk_rows_wave_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) key[j * 4 + c] = in ? f32_key(a[c]) : 0u;
     }
-    uint32_t T = 0;
-    for (int b = 31; b >= 0; --b) {
+    // Exact k-th largest key, bit by bit.  Long rows (J >= 8) search the top WP1 bits over the registers, then compact the keys
+    // that share that prefix — the only ones the remaining bits can tell apart, a few per cent of the row — into a wave-private
+    // LDS list and finish the search on those (`above` = keys beyond the prefix range, known from the last rejected step):
+    // 12 x 4J + 20 x ~2 compares per lane instead of 32 x 4J.  Rows whose list would not fit (mostly equal values) carry on
+    // over the registers.
+    constexpr int WP1 = J >= 8 ? 12 : 32, WR = 32 - WP1, WCAP = 512;
+    __shared__ uint32_t wbuf[J >= 8 ? 4 * WCAP : 1];
+    uint32_t T = 0, above = 0;
+#pragma unroll 1
+    for (int b = 31; b >= WR; --b) {
         const uint32_t cand = T | (1u << b);
         uint32_t c = 0;
 #pragma unroll
         for (int e = 0; e < J * 4; ++e) c += key[e] >= cand ? 1u : 0u;
-        if (wave_sum_u32(c) >= (uint32_t)k) T = cand;
+        c = wave_sum_u32(c);
+        if (c >= (uint32_t)k) T = cand; else above = c;
+    }
+    if (J >= 8) {
+        uint32_t* buf = wbuf + (threadIdx.x >> 6) * WCAP;
+        const uint32_t pre = T >> WR;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int e = 0; e < J * 4; ++e) {
+            const bool m = (key[e] >> WR) == pre;
+            const unsigned long long bal = __ballot(m);
+            if (bal == 0ull) continue;
+            if (m) {
+                const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < (uint32_t)WCAP) buf[pos] = key[e];
+            }
+            cnt += (uint32_t)__popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();                 // (the list is this wave's own: LDS serves a wave's accesses in order)
+        if (cnt <= (uint32_t)WCAP) {
+            uint32_t ck[WCAP / 64];
+#pragma unroll
+            for (int q = 0; q < WCAP / 64; ++q) ck[q] = (uint32_t)(q * 64 + lane) < cnt ? buf[q * 64 + lane] : 0u;
+            const int nq = (int)((cnt + 63u) >> 6);
+#pragma unroll 1
+            for (int b = WR - 1; b >= 0; --b) {
+                const uint32_t cand = T | (1u << b);
+                uint32_t c = 0;
+#pragma unroll
+                for (int q = 0; q < WCAP / 64; ++q) if (q < nq) c += ck[q] >= cand ? 1u : 0u;
+                if (above + wave_sum_u32(c) >= (uint32_t)k) T = cand;
+            }
+        } else {
+#pragma unroll 1
+            for (int b = WR - 1; b >= 0; --b) {
+                const uint32_t cand = T | (1u << b);
+                uint32_t c = 0;
+#pragma unroll
+                for (int e = 0; e < J * 4; ++e) c += key[e] >= cand ? 1u : 0u;
+                if (wave_sum_u32(c) >= (uint32_t)k) T = cand;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     uint32_t cgt = 0, ceq = 0;
 #pragma unroll
@@ -627,10 +681,16 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
     // per row dominates: 4.5 vs 0.36 ms)
     if (reg_ok && (F <= 2048 || (!idx_out && F <= 6144)) && !diag_env("CLT_TOPK_NO_WAVE")) {
         const dim3 grid((unsigned)((rows + 3) / 4));
-#define TKW(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
-                                   row_cnt, col_cnt, (long)rows)
+#define TKW(J_) do { if (idx_out) hipLaunchKernelGGL((topk_rows_wave_kernel<J_, true>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
+                                                     row_cnt, col_cnt, (long)rows); \
+                     else hipLaunchKernelGGL((topk_rows_wave_kernel<J_, false>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
+                                             row_cnt, col_cnt, (long)rows); } while (0)
         const int groups = (F + 255) / 256;
-        if (groups <= 4) TKW(4); else if (groups <= 8) TKW(8); else if (groups <= 16) TKW(16); else TKW(24);
+        // (list output only reaches here with F <= 2048: the longer instantiations are dense-only)
+#define TKWD(J_) hipLaunchKernelGGL((topk_rows_wave_kernel<J_, false>), grid, dim3(256), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, \
+                                    row_cnt, col_cnt, (long)rows)
+        if (groups <= 4) TKW(4); else if (groups <= 8) TKW(8); else if (idx_out) return CLT_ERR_RANGE; else if (groups <= 16) TKWD(16); else TKWD(24);
+#undef TKWD
 #undef TKW
         CLT_LAUNCH_CHECK(); return CLT_OK;
     }

@@ -2,7 +2,7 @@
 # TopK-aux step: tests of the compacted pass, then bench A/B of the switches named on the command line (VAR=0 vs default)
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 400 python -u -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -x -q --timeout 180 --timeout-method thread -k "columns or compact or aux or mask_positive or weight_prep" > gpurun_out/aux_tests.log 2>&1 || { tail -30 gpurun_out/aux_tests.log; exit 1; }
+timeout -k 10 400 python -u -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -x -q --timeout 180 --timeout-method thread -k "columns or compact or aux or mask_positive or weight_prep or topk_rows or selection" > gpurun_out/aux_tests.log 2>&1 || { tail -30 gpurun_out/aux_tests.log; exit 1; }
 tail -2 gpurun_out/aux_tests.log
 for var in "$@"; do
   for v in 0 1; do

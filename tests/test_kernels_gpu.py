@@ -746,3 +746,28 @@ def test_weight_prep_gather_equals_prep_of_gathered_rows(ops):
     op, opT = ops.weight_prep_gather_bf16(w, cidx)
     assert (cidx < 0).any()
     assert torch.equal(op.view(torch.int16), ref_op.view(torch.int16)) and torch.equal(opT.view(torch.int16), ref_T.view(torch.int16))
+
+
+@pytest.mark.parametrize("F,k", [(1100, 16), (2048, 100), (2500, 512), (4100, 16), (5000, 512), (6144, 1000)])
+def test_topk_rows_wave_two_phase_search(ops, F, k):
+    """Short-row per-row TopK (one wave per row): the k-th key is searched over the registers for the top 12 bits and over the
+    compacted prefix matches for the rest; rows with more matches than the list holds (quantised values: heavy ties) carry on
+    over the registers.  Bit-exact with the oracle either way, -inf masked entries and list output (F <= 2048) included."""
+    g = torch.Generator().manual_seed(F + k)
+    x = torch.randn(37, 2, F, generator=g)
+    x[3] = torch.randint(0, 4, (2, F), generator=g).float() - 1.0          # 4 levels: ~F/4 ties at the k-th value
+    x[5] = 0.37                                                            # one value: every key shares the prefix
+    x[7] = torch.where(torch.rand(2, F, generator=g) < 0.9, torch.full((2, F), -float("inf")), x[7])
+    x[9] = (x[9] * 64).round() / 64                                        # many small tie groups
+    ref, ridx = O.per_layer_topk_fwd(x, k)
+    xd = x.to(DEV)
+    assert torch.equal(ops.topk_rows(xd, k).cpu(), ref)
+    if F <= 2048:
+        f, idx, val = ops.topk_rows(xd, k, want_compact=True)
+        assert torch.equal(f.cpu(), ref)
+        dense = torch.zeros(37 * 2, F)
+        ii, vv = idx.cpu().long(), val.cpu()
+        for r in range(37 * 2):
+            m = ii[r] >= 0
+            dense[r, ii[r][m]] = vv[r][m]
+        assert torch.equal(dense.view(37, 2, F), ref)
