@@ -566,8 +566,16 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 // its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
 // GATHER: output row r of group g is input row ridx[g * rows + r] of the group's src_rows input rows (< 0: a zero row) — the
 // compacted TopK-aux pass preps the dead rows of the decoder matrices without a gathered fp32 copy in between.
+// (occupancy hints, measured as variants — scripts/gpu_waves_ab.sh: weight_prep at 2 / 3 / 4 waves per SIMD 617 / 795 / 1070 us
+// per PLT decoder, the tighter register budgets spill; the JumpReLU loss pass at 3 / 4: PLT step 21.5 / 22.1 ms)
+#ifndef WP_WAVES
+#define WP_WAVES 2
+#endif
+#ifndef JL_WAVES
+#define JL_WAVES 3
+#endif
 template <bool F16, bool GATHER = false>
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WP_WAVES))) void weight_prep_kernel(const float* __restrict__ W, int rows, int n, uint16_t* __restrict__ op,
                                                           uint16_t* __restrict__ opT, float* __restrict__ sq, int accumulate,
                                                           const int32_t* __restrict__ ridx = nullptr, int src_rows = 0) {
     __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 // grid (ceil(n/256), ceil(rows/256)): a block walks 4 row tiles of its 256 columns, keeping the column partial sums in
 // registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
 template <bool XB, bool GB, bool TANH, bool F16>
-__global__ __launch_bounds__(256) void jumprelu_loss_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JL_WAVES))) void jumprelu_loss_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
                                                                  const float* __restrict__ sq, const void* __restrict__ dfm, float bw,
                                                                  float lamB, float c, float coefBL,
                                                                  uint16_t* __restrict__ dpreT, float* __restrict__ part,
