@@ -104,7 +104,10 @@ int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t c
 int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
                                 float e, void* ws, size_t wsb, hipStream_t st, const int32_t* gate);
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
-                           const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st);
+                           const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st,
+                           void* ws = nullptr, size_t wsb = 0);
+// scratch the list-output form of long rows wants (two streaming passes, select.hip); 0: that form does not apply
+size_t clt_internal_topk_rows_workspace_bytes(long rows, int F, int k);
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
                               hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false);

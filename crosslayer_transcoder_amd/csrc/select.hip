@@ -661,8 +661,199 @@ void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// mode 0, long rows, k <= 64, list output: two streaming passes of independent WAVES — no block barrier anywhere, so the
+// chip is filled by occupancy instead of one persistent block per CU waiting at a dozen barriers per row.
+//   pass A  one wave per 2048-element chunk of a row (32 keys per lane, one coalesced read of the row): the chunk's own top k
+//           in the selection's order (key descending, index ascending), positive values only -> k (key, index) slots.
+//           Lower bound = k-th largest of the 64 per-lane maxima (ballot search, scalar work only); the ~1.5 k candidates
+//           above it go one per lane through a 512-byte wave-private LDS list, and their exact k-th key is a second ballot
+//           search.  Chunks with more than 64 candidates (heavy ties) extract their maxima one by one from the registers.
+//   pass B  one wave per row: exact top k of the row's chunks * k slots (bit search over <= 16 registers per lane), ties by
+//           index, written in ascending feature order as the compact row the list construction reads.
+// The row's top k is contained in the union of its chunks' top k under the same total order.
+// ------------------------------------------------------------------------------------------------
+constexpr int CHK = 2048;
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ x, int F, int k, const uint8_t* __restrict__ col_mask,
+                                                         int L, long nrows, int chunks, uint32_t* __restrict__ okey,
+                                                         int32_t* __restrict__ oidx) {
+    __shared__ uint32_t lkey[4][64];
+    __shared__ int32_t lidx[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long gw = (long)blockIdx.x * 4 + wv;
+    if (gw >= nrows * chunks) return;                     // (whole waves leave; nothing below synchronises the block)
+    const long row = gw / chunks;
+    const int base = (int)(gw - row * chunks) * CHK;
+    const float* xr = x + row * F;
+    const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+    uint32_t key[32];
+    uint32_t tmax = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i0 = base + (j * 64 + lane) * 4;
+        const bool in = i0 < F;
+        const int ic = in ? i0 : base;
+        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
+        float a[4] = {v.x, v.y, v.z, v.w};
+        if (mk) {
+            const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
+            a[0] = m4.x ? a[0] : -INFINITY; a[1] = m4.y ? a[1] : -INFINITY; a[2] = m4.z ? a[2] : -INFINITY; a[3] = m4.w ? a[3] : -INFINITY;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t kk = in ? f32_key(a[c]) : 0u; key[j * 4 + c] = kk; tmax = max(tmax, kk); }
+    }
+    constexpr uint32_t POS = 0x80000001u;                 // smallest key of a value > 0: nothing else is ever emitted
+    uint32_t LB = wave_kth(tmax, (uint32_t)k);            // at least k keys of the chunk are >= LB (distinct lanes; k <= 64)
+    LB = max(LB, POS);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const bool c = key[e] >= LB;
+        const unsigned long long bal = __ballot(c);
+        if (bal == 0ull) continue;
+        if (c) {
+            const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < 64u) { lkey[wv][pos] = key[e]; lidx[wv][pos] = base + ((e >> 2) * 64 + lane) * 4 + (e & 3); }
+        }
+        cnt += (uint32_t)__popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();                      // (the list is this wave's own: LDS serves a wave's accesses in order)
+    uint32_t* ok = okey + gw * k;
+    int32_t* oi = oidx + gw * k;
+    if (cnt <= 64u) {
+        const bool have = (uint32_t)lane < cnt;
+        const uint32_t ck = have ? lkey[wv][lane] : 0u;
+        const int ci = have ? lidx[wv][lane] : 0x7fffffff;
+        bool sel = have;
+        if (cnt > (uint32_t)k) {
+            const uint32_t T = wave_kth(ck, (uint32_t)k);
+            const bool gt = ck > T, eq = have && ck == T;
+            const uint32_t ngt = (uint32_t)__popcll(__ballot(gt)), neq = (uint32_t)__popcll(__ballot(eq)), krem = (uint32_t)k - ngt;
+            sel = gt || eq;
+            if (neq > krem) {                              // more ties than places: the lower indices win
+                uint32_t rank = 0;
+                unsigned long long tb = __ballot(eq);
+                while (tb) {
+                    const int l = __builtin_ctzll(tb);
+                    tb &= tb - 1ull;
+                    rank += __shfl(ci, l, 64) < ci ? 1u : 0u;
+                }
+                sel = gt || (eq && rank < krem);
+            }
+        }
+        const unsigned long long sb = __ballot(sel);
+        const int n = __popcll(sb);
+        if (sel) { const int pos = __popcll(sb & ((1ull << lane) - 1ull)); ok[pos] = ck; oi[pos] = ci; }
+        if (lane >= n && lane < k) { ok[lane] = 0u; oi[lane] = -1; }
+    } else {
+        int s = 0;
+        for (; s < k; ++s) {                               // (wave-uniform loop) the next entry in the selection's order
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) m = max(m, key[e]);
+            m = wave_max_u32(m);
+            if (m < POS) break;
+            int mi = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) if (key[e] == m) mi = min(mi, base + ((e >> 2) * 64 + lane) * 4 + (e & 3));
+            mi = wave_min_i32(mi);
+            if (lane == 0) { ok[s] = m; oi[s] = mi; }
+#pragma unroll
+            for (int e = 0; e < 32; ++e) if (key[e] == m && base + ((e >> 2) * 64 + lane) * 4 + (e & 3) == mi) key[e] = 0u;
+        }
+        if (lane >= s && lane < k) { ok[lane] = 0u; oi[lane] = -1; }
+    }
+}
+
+template <int NQ>                                      // slots per lane: chunks * k <= 64 * NQ
+__global__ __launch_bounds__(256) void topk_merge_kernel(const uint32_t* __restrict__ ckey, const int32_t* __restrict__ cidx, int n, int k,
+                                                         int F, int L, long nrows, int32_t* __restrict__ idx_out,
+                                                         float* __restrict__ val_out, uint32_t* __restrict__ row_cnt,
+                                                         uint32_t* __restrict__ col_cnt) {
+    __shared__ int32_t sidx[4][64];
+    __shared__ uint32_t skey[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wv;
+    if (row >= nrows) return;
+    uint32_t kq[NQ];
+    int iq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int p = q * 64 + lane;
+        kq[q] = p < n ? ckey[row * n + p] : 0u;
+        iq[q] = p < n ? cidx[row * n + p] : 0x7fffffff;
+    }
+    uint32_t T = 0;                                       // exact k-th largest slot key (0: fewer than k slots are filled)
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c += kq[q] >= cand ? 1u : 0u;
+        if (wave_sum_u32(c) >= (uint32_t)k) T = cand;
+    }
+    uint32_t cgt = 0, ceq = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { cgt += kq[q] > T ? 1u : 0u; ceq += (kq[q] == T && kq[q] != 0u) ? 1u : 0u; }
+    const uint32_t ngt = wave_sum_u32(cgt), neq = wave_sum_u32(ceq), krem = (uint32_t)k - ngt;
+    uint32_t rank[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rank[q] = 0;
+    if (T != 0u && neq > krem) {                          // (wave-uniform) more ties than places: the lower indices win
+#pragma unroll
+        for (int q2 = 0; q2 < NQ; ++q2) {
+            unsigned long long tb = __ballot(kq[q2] == T);
+            while (tb) {
+                const int l = __builtin_ctzll(tb);
+                tb &= tb - 1ull;
+                const int o = __shfl(iq[q2], l, 64);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) rank[q] += (kq[q] == T && o < iq[q]) ? 1u : 0u;
+            }
+        }
+    }
+    uint32_t nsel = 0;                                    // selected slots (<= k) into the wave's list, arrival order
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool sel = kq[q] != 0u && (kq[q] > T || (kq[q] == T && rank[q] < krem)) && key_f32(kq[q]) > 0.0f;
+        const unsigned long long sb = __ballot(sel);
+        if (sb == 0ull) continue;
+        if (sel) { const uint32_t pos = nsel + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull)); sidx[wv][pos] = iq[q]; skey[wv][pos] = kq[q]; }
+        nsel += (uint32_t)__popcll(sb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool have = (uint32_t)lane < nsel;
+    const int me = have ? sidx[wv][lane] : 0x7fffffff;
+    const uint32_t mk = have ? skey[wv][lane] : 0u;
+    int pos = 0;                                          // ascending feature index (rank among the <= k selected)
+    for (uint32_t j = 0; j < nsel; ++j) pos += __shfl(me, (int)j, 64) < me ? 1 : 0;
+    if (have) {
+        idx_out[row * k + pos] = me; val_out[row * k + pos] = key_f32(mk);
+        if (col_cnt) atomicAdd(&col_cnt[(row % L) * F + me], 1u);
+    } else if (lane < k) { idx_out[row * k + lane] = -1; val_out[row * k + lane] = 0.0f; }
+    if (row_cnt && lane == 0) row_cnt[row] = nsel;
+}
+
+size_t clt_internal_topk_rows_workspace_bytes(long rows, int F, int k) {
+    if (k < 1 || k > 64 || F <= CHK || F % 4) return 0;
+    const long chunks = (F + CHK - 1) / CHK;
+    if (chunks * k > 1024) return 0;
+    return (size_t)rows * chunks * k * 8;
+}
+
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
-                           const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st) {
+                           const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st, void* ws, size_t wsb) {
     if (rows <= 0 || F <= 0 || k < 0 || L <= 0) return CLT_ERR_SHAPE;
     if (k > F) return CLT_ERR_K_GT_F;
     if ((idx_out != nullptr) != (val_out != nullptr)) return CLT_ERR_SHAPE;
@@ -672,6 +863,24 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
         if (feat && hipMemsetAsync(feat, 0, (size_t)rows * F * sizeof(float), st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (row_cnt && hipMemsetAsync(row_cnt, 0, (size_t)rows * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         return CLT_OK;
+    }
+    // list output of long rows with a workspace at hand: the two streaming passes
+    const size_t need = clt_internal_topk_rows_workspace_bytes(rows, F, k);
+    if (!feat && idx_out && ws && need && wsb >= need && aligned16(x) && (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) &&
+        !diag_env("CLT_TOPK_NO_CHUNKS")) {
+        const int chunks = (F + CHK - 1) / CHK, n = chunks * k;
+        const long waves = (long)rows * chunks;
+        if ((waves + 3) / 4 <= 0x7fffffffL) {
+            uint32_t* ck = (uint32_t*)ws;
+            int32_t* ci = (int32_t*)(ck + (size_t)waves * k);
+            hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, F, k, col_mask, L, (long)rows, chunks, ck, ci);
+            const dim3 mg((unsigned)((rows + 3) / 4));
+#define TKM(NQ_) hipLaunchKernelGGL((topk_merge_kernel<NQ_>), mg, dim3(256), 0, st, (const uint32_t*)ck, (const int32_t*)ci, n, k, F, L, (long)rows, \
+                                    idx_out, val_out, row_cnt, col_cnt)
+            if (n <= 256) TKM(4); else if (n <= 512) TKM(8); else TKM(16);
+#undef TKM
+            CLT_LAUNCH_CHECK(); return CLT_OK;
+        }
     }
     const bool reg_ok = F % 4 == 0 && F <= 32 * RT && (!idx_out || k <= 1024) && aligned16(x) && (!feat || aligned16(feat)) &&
                         (!col_mask || (reinterpret_cast<uintptr_t>(col_mask) & 3) == 0) && !diag_env("CLT_TOPK_ROWS_V1");
@@ -746,7 +955,7 @@ int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F
 
 extern "C" {
 int clt_topk_rows_f32(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out, void* st) {
-    return clt_internal_topk_rows(x, feat, rows, F, k, idx_out, val_out, nullptr, 1, nullptr, nullptr, as_stream(st));
+    return clt_internal_topk_rows(x, feat, rows, F, k, idx_out, val_out, nullptr, 1, nullptr, nullptr, as_stream(st), nullptr, 0);
 }
 
 size_t clt_topk_segmented_workspace_bytes(int B, int L, int F, int per_layer) {

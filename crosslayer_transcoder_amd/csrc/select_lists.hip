@@ -434,7 +434,8 @@ LPlan lplan(int B, int L, int F, int k, int mode, int world, int flags) {
         p.off_sample = p.off_ckey = p.off_cidx = o;
         p.off_sidx = take((size_t)p.rows * k * 4);          // compact indices [rows][k]
         p.off_sval = take((size_t)p.rows * k * 4);          // compact values
-        p.off_fbsel = p.off_fbbuild = o;
+        p.off_fbsel = take(clt_internal_topk_rows_workspace_bytes(p.rows, F, k));    // chunk candidates of the streaming form
+        p.off_fbbuild = o;
     } else {
         p.off_sample = take((size_t)p.S * p.ns * 4);
         p.off_ckey = take((size_t)p.S * p.capS * 4);
@@ -529,7 +530,8 @@ int run_stages(const SelArgs& a, int lo, int hi) {
         } else if (mode == 0) {
             if (stage != last_stage) continue;
             int32_t* ci = (int32_t*)sidx;
-            const int rc = clt_internal_topk_rows(a.x, nullptr, rows, F, k, ci, sval, a.col_mask, L, row_cnt, col_cnt, st);
+            const int rc = clt_internal_topk_rows(a.x, nullptr, rows, F, k, ci, sval, a.col_mask, L, row_cnt, col_cnt, st,
+                                                  w8 + p.off_fbsel, p.off_fbbuild - p.off_fbsel);
             if (rc != CLT_OK) return rc;
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
             hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, ci, sval, k, F, L, rows, a.row_start, a.cap,

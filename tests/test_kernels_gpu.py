@@ -771,3 +771,27 @@ def test_topk_rows_wave_two_phase_search(ops, F, k):
             m = ii[r] >= 0
             dense[r, ii[r][m]] = vv[r][m]
         assert torch.equal(dense.view(37, 2, F), ref)
+
+
+@pytest.mark.parametrize("F,k", [(4100, 16), (8192, 64), (20000, 16), (32768, 16), (32768, 31), (2052, 5)])
+def test_select_rows_streaming_chunks(ops, F, k):
+    """PerLayerTopK straight to lists on long rows: one wave per 2048-element chunk keeps the chunk's own top k, one wave per
+    row merges them.  Bit-exact with the oracle's rule (larger value, then lower index) on random rows, rows of a few levels
+    (every chunk overflows its one-per-lane candidate list: the extract-max path), a constant row, rows with fewer than k
+    positive values, mostly -inf rows, ties cut across chunks, and under the dead-feature mask."""
+    g = torch.Generator().manual_seed(F + k)
+    x = torch.randn(21, 2, F, generator=g)
+    x[2] = torch.randint(0, 4, (2, F), generator=g).float() - 1.0
+    x[4] = 0.37
+    x[6] = -x[6].abs()
+    x[6, 0, 5] = 1.5; x[6, 0, F - 1] = 0.25; x[6, 1, 2049 % F] = 2.0
+    x[8] = torch.where(torch.rand(2, F, generator=g) < 0.98, torch.full((2, F), -float("inf")), x[8])
+    x[10] = (x[10] * 8).round() / 8
+    x[12, :, :] = 0.0
+    x[12, 0, ::700] = 3.0                                                   # equal values spread over the chunks
+    mask = (torch.rand(2, F, generator=g) < 0.3).to(torch.uint8)
+    xd = x.to(DEV)
+    for cm in (None, mask):
+        xm = x if cm is None else torch.where(cm.bool().expand_as(x), x, torch.full_like(x, -float("inf")))
+        got = ops.select_lists(xd, k, ops.SELECT_ROWS, col_mask=None if cm is None else cm.to(DEV))
+        assert torch.equal(ops.sparse_scatter_dense(got, got.csc_val).cpu(), O.per_layer_topk_fwd(xm, k)[0])
