@@ -685,10 +685,25 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
+// k-th largest of the 64 lane values, searched on the top 16 key bits only (lower bits zero): a LOWER bound of it — at
+// least m lanes hold values >= the result — at half the steps of the exact search
+__device__ __forceinline__ uint32_t wave_kth_hi16(uint32_t v, uint32_t m) {
+    uint32_t t = 0;
+    for (int b = 30; b >= 16; b -= 2) {
+        const uint32_t c1 = (uint32_t)__popcll(__ballot(v >= (t | (1u << b))));
+        const uint32_t c2 = (uint32_t)__popcll(__ballot(v >= (t | (2u << b))));
+        const uint32_t c3 = (uint32_t)__popcll(__ballot(v >= (t | (3u << b))));
+        if (c3 >= m) t |= 3u << b;
+        else if (c2 >= m) t |= 2u << b;
+        else if (c1 >= m) t |= 1u << b;
+    }
+    return t;
+}
+
 __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ x, int F, int k, const uint8_t* __restrict__ col_mask,
                                                          int L, long nrows, int chunks, uint32_t* __restrict__ okey,
                                                          int32_t* __restrict__ oidx) {
-    __shared__ uint32_t lkey[4][64];
+    __shared__ float lval[4][64];
     __shared__ int32_t lidx[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long gw = (long)blockIdx.x * 4 + wv;
@@ -697,34 +712,35 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
     const int base = (int)(gw - row * chunks) * CHK;
     const float* xr = x + row * F;
     const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
-    uint32_t key[32];
-    uint32_t tmax = 0;
+    // (the values stay floats: only positive ones can be emitted, and among those float order = key order)
+    float a[32];
+    float tmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i0 = base + (j * 64 + lane) * 4;
         const bool in = i0 < F;
         const int ic = in ? i0 : base;
         const float4 v = *reinterpret_cast<const float4*>(xr + ic);
-        float a[4] = {v.x, v.y, v.z, v.w};
+        float q[4] = {v.x, v.y, v.z, v.w};
         if (mk) {
             const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
-            a[0] = m4.x ? a[0] : -INFINITY; a[1] = m4.y ? a[1] : -INFINITY; a[2] = m4.z ? a[2] : -INFINITY; a[3] = m4.w ? a[3] : -INFINITY;
+            q[0] = m4.x ? q[0] : -INFINITY; q[1] = m4.y ? q[1] : -INFINITY; q[2] = m4.z ? q[2] : -INFINITY; q[3] = m4.w ? q[3] : -INFINITY;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const uint32_t kk = in ? f32_key(a[c]) : 0u; key[j * 4 + c] = kk; tmax = max(tmax, kk); }
+        for (int c = 0; c < 4; ++c) { const float vv = in ? q[c] : -INFINITY; a[j * 4 + c] = vv; tmax = fmaxf(tmax, vv); }
     }
     constexpr uint32_t POS = 0x80000001u;                 // smallest key of a value > 0: nothing else is ever emitted
-    uint32_t LB = wave_kth(tmax, (uint32_t)k);            // at least k keys of the chunk are >= LB (distinct lanes; k <= 64)
-    LB = max(LB, POS);
+    // at least k values of the chunk (k distinct lanes' maxima; k <= 64) are >= LB
+    const float LB = key_f32(max(wave_kth_hi16(f32_key(tmax), (uint32_t)k), POS));
     uint32_t cnt = 0;
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-        const bool c = key[e] >= LB;
+        const bool c = a[e] >= LB;
         const unsigned long long bal = __ballot(c);
         if (bal == 0ull) continue;
         if (c) {
             const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < 64u) { lkey[wv][pos] = key[e]; lidx[wv][pos] = base + ((e >> 2) * 64 + lane) * 4 + (e & 3); }
+            if (pos < 64u) { lval[wv][pos] = a[e]; lidx[wv][pos] = base + ((e >> 2) * 64 + lane) * 4 + (e & 3); }
         }
         cnt += (uint32_t)__popcll(bal);
     }
@@ -732,45 +748,39 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
     uint32_t* ok = okey + gw * k;
     int32_t* oi = oidx + gw * k;
     if (cnt <= 64u) {
+        // one candidate per lane: each ranks itself in the selection's order (value descending, index ascending) against the
+        // others, read lane by lane through scalar registers; the first k of that order are the chunk's selection
         const bool have = (uint32_t)lane < cnt;
-        const uint32_t ck = have ? lkey[wv][lane] : 0u;
+        const float cv = have ? lval[wv][lane] : -INFINITY;
         const int ci = have ? lidx[wv][lane] : 0x7fffffff;
-        bool sel = have;
+        uint32_t rank = 0;
         if (cnt > (uint32_t)k) {
-            const uint32_t T = wave_kth(ck, (uint32_t)k);
-            const bool gt = ck > T, eq = have && ck == T;
-            const uint32_t ngt = (uint32_t)__popcll(__ballot(gt)), neq = (uint32_t)__popcll(__ballot(eq)), krem = (uint32_t)k - ngt;
-            sel = gt || eq;
-            if (neq > krem) {                              // more ties than places: the lower indices win
-                uint32_t rank = 0;
-                unsigned long long tb = __ballot(eq);
-                while (tb) {
-                    const int l = __builtin_ctzll(tb);
-                    tb &= tb - 1ull;
-                    rank += __shfl(ci, l, 64) < ci ? 1u : 0u;
-                }
-                sel = gt || (eq && rank < krem);
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), (int)j));
+                const int ij = __builtin_amdgcn_readlane(ci, (int)j);
+                rank += (vj > cv || (vj == cv && ij < ci)) ? 1u : 0u;
             }
         }
+        const bool sel = have && rank < (uint32_t)k;
         const unsigned long long sb = __ballot(sel);
         const int n = __popcll(sb);
-        if (sel) { const int pos = __popcll(sb & ((1ull << lane) - 1ull)); ok[pos] = ck; oi[pos] = ci; }
+        if (sel) { const int pos = __popcll(sb & ((1ull << lane) - 1ull)); ok[pos] = f32_key(cv); oi[pos] = ci; }
         if (lane >= n && lane < k) { ok[lane] = 0u; oi[lane] = -1; }
     } else {
         int s = 0;
         for (; s < k; ++s) {                               // (wave-uniform loop) the next entry in the selection's order
-            uint32_t m = 0;
+            float m = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) m = max(m, key[e]);
-            m = wave_max_u32(m);
-            if (m < POS) break;
+            for (int e = 0; e < 32; ++e) m = fmaxf(m, a[e]);
+            m = key_f32(wave_max_u32(f32_key(m)));
+            if (!(m > 0.0f)) break;
             int mi = 0x7fffffff;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) if (key[e] == m) mi = min(mi, base + ((e >> 2) * 64 + lane) * 4 + (e & 3));
+            for (int e = 0; e < 32; ++e) if (a[e] == m) mi = min(mi, base + ((e >> 2) * 64 + lane) * 4 + (e & 3));
             mi = wave_min_i32(mi);
-            if (lane == 0) { ok[s] = m; oi[s] = mi; }
+            if (lane == 0) { ok[s] = f32_key(m); oi[s] = mi; }
 #pragma unroll
-            for (int e = 0; e < 32; ++e) if (key[e] == m && base + ((e >> 2) * 64 + lane) * 4 + (e & 3) == mi) key[e] = 0u;
+            for (int e = 0; e < 32; ++e) if (a[e] == m && base + ((e >> 2) * 64 + lane) * 4 + (e & 3) == mi) a[e] = -INFINITY;
         }
         if (lane >= s && lane < k) { ok[lane] = 0u; oi[lane] = -1; }
     }
