@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (kernel experiments are built as variants of this file — `make variant V=n` defines GEMM_VARIANT — and compared in one
 // process by scripts/gemm_ab.py; tried and rejected in round 2, all slower or equal on the shapes of the step: DMA pieces
 // spread over the MFMA groups instead of issued together, s_setprio around the MFMA groups, the bias as the initial
-// accumulator, an integer maximum-and-compare scan in the select epilogue: profiles/r02_gemm_ab.md)
+// accumulator, an integer maximum-and-compare scan in the select epilogue, a staggered start of the persistent blocks: profiles/r02_gemm_ab.md)
 #ifndef GEMM_VARIANT
 #define GEMM_VARIANT 0
 #endif
