@@ -88,3 +88,26 @@ def test_headline_configuration_properties():
         engine.FUSE_ENCODER_SELECT = True
         cta.set_precision("32")
         torch.cuda.empty_cache()
+
+
+def test_perlayer_topk_streaming_selection_full_size():
+    """PerLayerTopK straight to lists at the headline shape (49152 rows x 32768, k = 16): the two streaming passes (chunk top
+    k, row merge) select, row by row, exactly what the dense-output per-row kernel selects (itself oracle-checked at small
+    sizes); every row holds k entries, in ascending feature order, and the column counts add up."""
+    from crosslayer_transcoder_amd import ops
+    B, L, F, k = 4096, 12, 32768, 16
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    x = torch.randn(B, L, F, device="cuda:0", generator=g)
+    x[7, 3] = 0.5                                        # a constant row: ties resolved by the lowest indices
+    x[9, 1] = -1.0                                       # nothing positive: an empty row
+    S = ops.select_lists(x, k, ops.SELECT_ROWS)
+    dense = ops.topk_rows(x, k)
+    assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val), dense)
+    rs = S.row_start.long()
+    cnt = (rs[1:] - rs[:-1]).view(B, L)
+    assert int(cnt[9, 1]) == 0 and int(cnt[7, 3]) == k
+    cnt[9, 1] = k
+    assert bool((cnt == k).all())
+    assert torch.equal(S.ent_col[int(rs[7 * L + 3]):int(rs[7 * L + 3]) + k].cpu() - 3 * F, torch.arange(k, dtype=torch.int32))
+    del dense
+    torch.cuda.empty_cache()
