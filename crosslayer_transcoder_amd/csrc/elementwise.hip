@@ -197,6 +197,12 @@ __global__ void mse_kernel(const float* __restrict__ r, const float* __restrict_
 // loss sum, d(loss)/d(recons) as the bf16 rows the weight pass gathers, and its column sums (the decoder bias gradient).
 // One pass instead of mse + cast + column_sum, and no fp32 gradient tensor.  Block = 64 rows x 256 columns (a wave per
 // row, 4 columns per lane); part_c: [gridDim.y][n] column partials, part_l: [gridDim.x * gridDim.y] loss partials.
+// Guarded 16-byte load, branch-free: an out-of-range element reads the tensor's first element instead and is replaced by zero
+// (see the tile passes below: a load inside `if (in_range)` is not hoisted, and the wave then has two loads in flight, not sixteen)
+__device__ __forceinline__ float4 ld4z(const float* __restrict__ base, long idx, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? idx : 0));
+    return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+}
 constexpr int MF_R = 64;                                // (32 / 16 / 8 rows per block measured equal or slower on a cold cache)
 constexpr int MF_U = MF_R / 4 < 8 ? MF_R / 4 : 8;      // rows a thread has in flight
 template <bool F16>
@@ -224,10 +230,8 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < MF_U; ++u) {
             const int row = r0 + w + 4 * (i0 + u);
-            if (cin && row < rows) {
-                rv[u] = *reinterpret_cast<const float4*>(r + (long)row * n + col);
-                yv[u] = *reinterpret_cast<const float4*>(y + (long)row * yrs + col);
-            }
+            rv[u] = ld4z(r, (long)row * n + col, cin && row < rows);
+            yv[u] = ld4z(y, (long)row * yrs + col, cin && row < rows);
         }
         // (the bf16 rows leave by 16-byte stores where the shape allows: neighbouring lanes trade the halves of two rows — the
         // even lane stores 8 columns of row u, the odd lane 8 columns of row u + 1; 8-byte stores run at about half the rate)
@@ -510,6 +514,14 @@ template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4(const v
     return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
 }
 
+// Guarded loads of the tile passes, branch-free: an out-of-range element reads the tensor's first element instead and is
+// replaced by zero.  (A load inside `if (in_range)` cannot be hoisted by the compiler: every guarded load pair then sits in its
+// own exec-masked block followed by s_waitcnt vmcnt(0), and a wave has two loads in flight instead of sixteen.)
+template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4z(const void* __restrict__ base, long idx, bool ok) {
+    const float4 v = act_load4<BF, F16>(base, ok ? idx : 0);
+    return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+}
+
 // grid (ceil(n/256), ceil(rows/64)); rows % 8 == 0, n % 4 == 0
 template <bool XB, bool F16>
 __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta, int rows,
@@ -529,8 +541,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
-            vv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (cin && row < rows) vv[u] = act_load4<XB, F16>(x, (long)row * n + col);
+            vv[u] = act_load4z<XB, F16>(x, (long)row * n + col, cin && row < rows);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -598,16 +609,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WP_WAVES)))
     for (long c0 = 0; c0 < n; c0 += FT_C) {
         const long col = c0 + 4 * tx;
         const bool cin = col < n;
+        float4 vv[16];                                      // all 16 rows of this thread requested before any is used
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + 2 * (w + 4 * (i >> 1)) + (i & 1);
+            const long sr = GATHER ? (long)srow[GATHER ? i : 0] : (long)row;
+            vv[i] = ld4z(W, sr * n + col, cin && (GATHER ? sr >= 0 : row < rows));
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                       // row pair w + 4 i: rows 2 (w + 4 i), + 1
             const int pr = w + 4 * i, row = r0 + 2 * pr;
             float f[2][4];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const long sr = GATHER ? (long)srow[GATHER ? 2 * i + e : 0] : (long)(row + e);
-                const bool in = cin && (GATHER ? sr >= 0 : row + e < rows);
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (in) v = *reinterpret_cast<const float4*>(W + sr * n + col);
+                const float4 v = vv[2 * i + e];
                 acc[2 * i + e] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 f[e][0] = v.x; f[e][1] = v.y; f[e][2] = v.z; f[e][3] = v.w;
             }
@@ -676,11 +691,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JL_WAVES)))
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
-                v4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); g4[u] = v4[u];
-                if (cin && row < rows) {
-                    v4[u] = act_load4<XB, F16>(x, (long)row * n + col);
-                    g4[u] = act_load4<GB, F16>(dfm, (long)row * n + col);
-                }
+                v4[u] = act_load4z<XB, F16>(x, (long)row * n + col, cin && row < rows);
+                g4[u] = act_load4z<GB, F16>(dfm, (long)row * n + col, cin && row < rows);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -761,11 +773,8 @@ __global__ __launch_bounds__(256) void mask_positive_t_kernel(const float* __res
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
-                v4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); g4[u] = v4[u];
-                if (cin && row < rows) {
-                    v4[u] = *reinterpret_cast<const float4*>(feat + (long)row * n + col);
-                    g4[u] = *reinterpret_cast<const float4*>(dfeat + (long)row * n + col);
-                }
+                v4[u] = ld4z(feat, (long)row * n + col, cin && row < rows);
+                g4[u] = ld4z(dfeat, (long)row * n + col, cin && row < rows);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

@@ -534,20 +534,28 @@ void topk_rows_wave_kernel(const float* __restrict__ x, float* __restrict__ feat
     if (!LIST) idx_out = nullptr;
     const float* xr = x + row * F;
     const uint8_t* mk = col_mask ? col_mask + (row % L) * F : nullptr;
+    // (every load of the row is requested before the first is used: a mask test between the loads would put each in its own
+    // block behind a full wait, two loads in flight per wave instead of J)
     uint32_t key[J * 4];
+    {
+        float4 raw[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int i0 = (j * 64 + lane) * 4;
-        const bool in = i0 < F;
-        const int ic = in ? i0 : 0;
-        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
-        float a[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < J; ++j) { const int i0 = (j * 64 + lane) * 4; raw[j] = *reinterpret_cast<const float4*>(xr + (i0 < F ? i0 : 0)); }
         if (mk) {
-            const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
-            a[0] = m4.x ? a[0] : -INFINITY; a[1] = m4.y ? a[1] : -INFINITY; a[2] = m4.z ? a[2] : -INFINITY; a[3] = m4.w ? a[3] : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int i0 = (j * 64 + lane) * 4;
+                const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + (i0 < F ? i0 : 0));
+                raw[j].x = m4.x ? raw[j].x : -INFINITY; raw[j].y = m4.y ? raw[j].y : -INFINITY;
+                raw[j].z = m4.z ? raw[j].z : -INFINITY; raw[j].w = m4.w ? raw[j].w : -INFINITY;
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) key[j * 4 + c] = in ? f32_key(a[c]) : 0u;
+        for (int j = 0; j < J; ++j) {
+            const bool in = (j * 64 + lane) * 4 < F;
+            key[j * 4 + 0] = in ? f32_key(raw[j].x) : 0u; key[j * 4 + 1] = in ? f32_key(raw[j].y) : 0u;
+            key[j * 4 + 2] = in ? f32_key(raw[j].z) : 0u; key[j * 4 + 3] = in ? f32_key(raw[j].w) : 0u;
+        }
     }
     // Exact k-th largest key, bit by bit.  Long rows (J >= 8) search the top WP1 bits over the registers, then compact the keys
     // that share that prefix — the only ones the remaining bits can tell apart, a few per cent of the row — into a wave-private
@@ -715,19 +723,26 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
     // (the values stay floats: only positive ones can be emitted, and among those float order = key order)
     float a[32];
     float tmax = -INFINITY;
+    {   // (all eight loads requested before the first is used; the mask, when there is one, in a second sweep)
+        float4 raw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i0 = base + (j * 64 + lane) * 4;
-        const bool in = i0 < F;
-        const int ic = in ? i0 : base;
-        const float4 v = *reinterpret_cast<const float4*>(xr + ic);
-        float q[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < 8; ++j) { const int i0 = base + (j * 64 + lane) * 4; raw[j] = *reinterpret_cast<const float4*>(xr + (i0 < F ? i0 : base)); }
         if (mk) {
-            const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + ic);
-            q[0] = m4.x ? q[0] : -INFINITY; q[1] = m4.y ? q[1] : -INFINITY; q[2] = m4.z ? q[2] : -INFINITY; q[3] = m4.w ? q[3] : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i0 = base + (j * 64 + lane) * 4;
+                const uchar4 m4 = *reinterpret_cast<const uchar4*>(mk + (i0 < F ? i0 : base));
+                raw[j].x = m4.x ? raw[j].x : -INFINITY; raw[j].y = m4.y ? raw[j].y : -INFINITY;
+                raw[j].z = m4.z ? raw[j].z : -INFINITY; raw[j].w = m4.w ? raw[j].w : -INFINITY;
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float vv = in ? q[c] : -INFINITY; a[j * 4 + c] = vv; tmax = fmaxf(tmax, vv); }
+        for (int j = 0; j < 8; ++j) {
+            const bool in = base + (j * 64 + lane) * 4 < F;
+            const float q[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float vv = in ? q[c] : -INFINITY; a[j * 4 + c] = vv; tmax = fmaxf(tmax, vv); }
+        }
     }
     constexpr uint32_t POS = 0x80000001u;                 // smallest key of a value > 0: nothing else is ever emitted
     // at least k values of the chunk (k distinct lanes' maxima; k <= 64) are >= LB

@@ -656,8 +656,8 @@ def test_fused_dense_jumprelu_tile_passes_bf16_inputs(ops, rows, L, F):
     for xin, din in ((x16, df16), (x16, df16.float()), (x16.float(), df16)):
         got = ops.jumprelu_loss_bwd_bf16(xin, theta, sq, din, 0.3, 0.01, 1.5, True, 1e-3)
         ref = ops.jumprelu_loss_bwd_bf16(x16.float(), theta, sq, df16.float(), 0.3, 0.01, 1.5, True, 1e-3)
-        for u, v in zip(got, ref):
-            assert torch.equal(u, v)
+        for u, v in zip(got, ref):              # (the fp64 loss sums: each instantiation's own fp32 contraction of the tile sums)
+            assert torch.equal(u, v) if u.dtype != torch.float64 else torch.allclose(u, v, rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("Bn,L,d,F", [(512, 2, 128, 512), (300, 3, 72, 264)])
