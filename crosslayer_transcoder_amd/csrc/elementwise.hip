@@ -166,11 +166,19 @@ __global__ void column_sum_kernel(const float* __restrict__ x, float* __restrict
 }
 
 // sums nb x k block partials (double) in block order; one block of 64 threads per output.
-__global__ void reduce_partials_kernel(const double* __restrict__ part, int nb, int k, double* __restrict__ out) {
+// (256 threads, four partials in flight per thread: one wave walking tens of thousands of block partials one dependent load
+// at a time took 84 us behind the dense JumpReLU loss pass)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, int nb, int k, double* __restrict__ out) {
+    __shared__ double sh[4];
     const int o = blockIdx.x;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) s += part[(long)b * k + o];
-    s = wave_sum_d(s);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 768 < nb; b += 1024) {
+        s0 += part[(long)b * k + o]; s1 += part[(long)(b + 256) * k + o];
+        s2 += part[(long)(b + 512) * k + o]; s3 += part[(long)(b + 768) * k + o];
+    }
+    for (; b < nb; b += 256) s0 += part[(long)b * k + o];
+    const double s = block_sum_d((s0 + s1) + (s2 + s3), sh);
     if (threadIdx.x == 0) out[o] = s;
 }
 
@@ -536,15 +544,23 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
     float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (theta && cin) th = *reinterpret_cast<const float4*>(theta + col);
     bool any[4] = {false, false, false, false};
-    for (int i0 = 0; i0 < 8; i0 += 2) {                    // two row pairs (four rows) loaded ahead of their arithmetic
-        float4 vv[4];
+// (variants measured at B*L*F = 1.61 G, bf16 in, scripts/jf_probe.py: 2 / 4 / 8 row pairs ahead 1966 / 1996 / 1987 us, 16-byte
+// row stores by lane exchange 1997 us: the pass writes twice what it reads and sits at ~4.9 TB/s either way)
+#ifndef JF_AHEAD
+#define JF_AHEAD 2
+#endif
+#ifndef JF_WIDE
+#define JF_WIDE 0
+#endif
+    for (int i0 = 0; i0 < 8; i0 += JF_AHEAD) {             // JF_AHEAD row pairs loaded ahead of their arithmetic
+        float4 vv[2 * JF_AHEAD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2 * JF_AHEAD; ++u) {
             const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
             vv[u] = act_load4z<XB, F16>(x, (long)row * n + col, cin && row < rows);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < JF_AHEAD; ++u) {
             const int pr = w + 4 * (i0 + u), row = r0 + 2 * pr;
             float f[2][4];
 #pragma unroll
@@ -556,9 +572,10 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
                 for (int k = 0; k < 4; ++k) any[k] |= f[e][k] > 0.0f;
                 // (8-byte stores: trading halves with the neighbour lane for 16-byte ones, as weight_prep_kernel does, measured
                 // 6 % slower here — this kernel is closer to instruction issue than to the store rate)
-                if (cin && row + e < rows)
+                if (!JF_WIDE && cin && row + e < rows)
                     *reinterpret_cast<uint2*>(feat + (long)(row + e) * n + col) = make_uint2(pack16<F16>(f[e][0], f[e][1]), pack16<F16>(f[e][2], f[e][3]));
             }
+            if (JF_WIDE) store_rowpair16<F16>(feat, row, n, col, tx, f[0], f[1], cin && row < rows, (n & 7) == 0);
             ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
         }
     }
@@ -1009,7 +1026,7 @@ int clt_mse_f32(const float* r, const float* y, long yrs, const float* mean, con
     if (!ws || wsb < clt_reduce_workspace_bytes(total)) return CLT_ERR_WORKSPACE;
     const int nb = blocks_for(total, TPB * 8, 2048);
     hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(TPB), 0, as_stream(st), r, y, yrs, mean, stdv, rows, n, gs, g, ys_out, (double*)ws);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)ws, nb, 1, loss_sum);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, as_stream(st), (const double*)ws, nb, 1, loss_sum);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 size_t clt_mse_bf16_colsum_workspace_bytes(int rows, int n) {
@@ -1092,7 +1109,7 @@ int clt_aux_mse_f32(const float* ar, const float* ys, const float* r, long total
     if (!ws || wsb < clt_reduce_workspace_bytes(total)) return CLT_ERR_WORKSPACE;
     const int nb = blocks_for(total, TPB * 8, 2048);
     hipLaunchKernelGGL(aux_mse_kernel, dim3(nb), dim3(TPB), 0, as_stream(st), ar, ys, r, total, gs, ga, gm, (double*)ws);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, as_stream(st), (const double*)ws, nb, 1, aux_sum);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, as_stream(st), (const double*)ws, nb, 1, aux_sum);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 int clt_row_sqnorm_f32(const float* W, int rows, int d, float* sq, int accumulate, void* st) {
@@ -1122,7 +1139,7 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
     double* ps = (double*)((char*)ws + align_up((size_t)2 * ch * n * sizeof(float), 16));
     hipLaunchKernelGGL(jumprelu_loss_kernel, dim3(gx, ch), dim3(TPB), 0, as_stream(st), x, theta, sq, dfm, bw, lamB, c,
                        use_tanh, coefBL, dpre, pth, pdn, ps, rows, n, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * ch, 3, sums);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(256), 0, as_stream(st), (const double*)ps, gx * ch, 3, sums);
     if (dfm) {
         hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pth, ch, n, dtheta, 0);
         hipLaunchKernelGGL(reduce_cols_kernel, dim3(gx), dim3(TPB), 0, as_stream(st), (const float*)pdn, ch, n, dnorm, 0);
@@ -1164,7 +1181,7 @@ int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, co
 #undef JLF
 #undef JL2
 #undef JL
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(64), 0, as_stream(st), (const double*)ps, gx * gy, 3, sums);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(256), 0, as_stream(st), (const double*)ps, gx * gy, 3, sums);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)part, gy, n, dtheta, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)gy * n), gy, n, dnorm, 0);
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(gc), dim3(TPB), 0, as_stream(st), (const float*)(part + (size_t)2 * gy * n), gy, n, dbias, 0);
