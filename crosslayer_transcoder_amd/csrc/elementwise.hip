@@ -207,8 +207,9 @@ __global__ void mse_kernel(const float* __restrict__ r, const float* __restrict_
 // row, 4 columns per lane); part_c: [gridDim.y][n] column partials, part_l: [gridDim.x * gridDim.y] loss partials.
 // Guarded 16-byte load, branch-free: an out-of-range element reads the tensor's first element instead and is replaced by zero
 // (see the tile passes below: a load inside `if (in_range)` is not hoisted, and the wave then has two loads in flight, not sixteen)
-__device__ __forceinline__ float4 ld4z(const float* __restrict__ base, long idx, bool ok) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? idx : 0));
+// (`safe`: an index that is always readable — 0 unless `base` is a rebased pointer whose element 0 lies outside the tensor)
+__device__ __forceinline__ float4 ld4z(const float* __restrict__ base, long idx, bool ok, long safe = 0) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? idx : safe));
     return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
 }
 constexpr int MF_R = 64;                                // (32 / 16 / 8 rows per block measured equal or slower on a cold cache)
@@ -238,8 +239,9 @@ __global__ __launch_bounds__(256) void mse_bf16_colsum_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < MF_U; ++u) {
             const int row = r0 + w + 4 * (i0 + u);
-            rv[u] = ld4z(r, (long)row * n + col, cin && row < rows);
-            yv[u] = ld4z(y, (long)row * yrs + col, cin && row < rows);
+            // (y was rebased by the layer offset above: its element 0 may lie outside the batch — the block's first row is safe)
+            rv[u] = ld4z(r, (long)row * n + col, cin && row < rows, (long)r0 * n);
+            yv[u] = ld4z(y, (long)row * yrs + col, cin && row < rows, (long)r0 * yrs);
         }
         // (the bf16 rows leave by 16-byte stores where the shape allows: neighbouring lanes trade the halves of two rows — the
         // even lane stores 8 columns of row u, the odd lane 8 columns of row u + 1; 8-byte stores run at about half the rate)
