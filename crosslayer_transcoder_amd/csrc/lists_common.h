@@ -169,6 +169,54 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     const float* xr = feat + row * F;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* th = theta ? theta + (row % L) * F : nullptr;
+    const int colbase = (int)(row % L) * F;
+    if (F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0) {
+        // 16-byte loads, a wave owns a quarter of the row (a multiple of 256 columns): count its entries, then place them in
+        // column order — lane l's four consecutive columns before lane l + 1's (four ballots give the offsets).  The second
+        // sweep finds the row in L2.  (The scalar form below read the row twice, 4 bytes per lane: 4.9 ms for 6.4 GB.)
+        const int seg = (F / 4 + 255) / 256 * 256;
+        const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
+        auto flags = [&](int i, bool in, float4& x, bool p[4]) {
+            const int ii = in ? i : 0;                     // (column 0 is always readable; F % 4 == 0, so i + 3 < F when in)
+            x = *reinterpret_cast<const float4*>(xr + ii);
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (th) t = *reinterpret_cast<const float4*>(th + ii);
+            p[0] = in && x.x > 0.0f && x.x > t.x; p[1] = in && x.y > 0.0f && x.y > t.y;
+            p[2] = in && x.z > 0.0f && x.z > t.z; p[3] = in && x.w > 0.0f && x.w > t.w;
+        };
+        uint32_t c = 0;
+        for (int base = s0; base < s1; base += 256) {
+            const int i = base + lane * 4;
+            float4 x; bool p[4];
+            flags(i, i < s1, x, p);
+            c += (uint32_t)p[0] + (uint32_t)p[1] + (uint32_t)p[2] + (uint32_t)p[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) wcnt[w] = c;
+        __syncthreads();
+        uint32_t off = row_start[row];
+        for (int k = 0; k < w; ++k) off += wcnt[k];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int base = s0; base < s1; base += 256) {
+            const int i = base + lane * 4;
+            float4 x; bool p[4];
+            flags(i, i < s1, x, p);
+            const unsigned long long b0 = __ballot(p[0]), b1 = __ballot(p[1]), b2 = __ballot(p[2]), b3 = __ballot(p[3]);
+            if ((b0 | b1 | b2 | b3) == 0ull) continue;
+            uint32_t pos = off + (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p[q]) {
+                    if (pos < cap) { ent_col[pos] = colbase + i + q; ent_val[pos] = xv[q]; }
+                    else *overflow = 1;
+                    ++pos;
+                }
+            off += (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        }
+        return;
+    }
     const int seg = ((F + 3) / 4 + 63) / 64 * 64;
     const int s0 = w * seg, s1 = min(F, s0 + seg);
     uint32_t c = 0;
@@ -179,7 +227,6 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     __syncthreads();
     uint32_t off = row_start[row];
     for (int k = 0; k < w; ++k) off += wcnt[k];
-    const int colbase = (int)(row % L) * F;
     for (int base = s0; base < s1; base += 64) {
         const int i = base + lane;
         const float v = i < s1 ? xr[i] : 0.0f;
