@@ -13,26 +13,38 @@ constexpr int LTPB = 256;
 // well: the lists of JumpReLU(feat) straight from the pre-activations (jumprelu.py:33-37: x * [(x > theta) & (x > 0)]).
 __device__ __forceinline__ bool list_entry(float x, const float* __restrict__ th, int col) { return x > 0.0f && (!th || x > th[col]); }
 
+// Segment of the row that wave w of the block owns, for both list-build kernels: a quarter of the row, whole 16-byte groups of
+// 64 lanes in the vector form.  wave_cnt (optional, [rows][4]): the per-wave counts, so that fill_rows_kernel need not count again.
+__device__ __forceinline__ bool rows_vec_form(const float* xr, const float* th, int F) {
+    return F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0;
+}
+__device__ __forceinline__ int rows_seg(int F, bool vec) { return vec ? (F / 4 + 255) / 256 * 256 : ((F + 3) / 4 + 63) / 64 * 64; }
+
 __global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
-                                                         uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on) {
+                                                         uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on,
+                                                         uint32_t* __restrict__ wave_cnt = nullptr) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     __shared__ uint32_t sh[4];
     const float* xr = feat + (long)blockIdx.x * F;
     const float* th = theta ? theta + (long)(blockIdx.x % L) * F : nullptr;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool vec = rows_vec_form(xr, th, F);
+    const int seg = rows_seg(F, vec);
+    const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
     uint32_t c = 0;
-    if (F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0) {          // 16-byte loads: the pass is a plain HBM stream
-        for (int i = threadIdx.x * 4; i < F; i += LTPB * 4) {
+    if (vec) {                                             // 16-byte loads: the pass is a plain HBM stream
+        for (int i = s0 + lane * 4; i < s1; i += 256) {
             const float4 x = *reinterpret_cast<const float4*>(xr + i);
             float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (th) t = *reinterpret_cast<const float4*>(th + i);
             c += (x.x > 0.0f && x.x > t.x) + (x.y > 0.0f && x.y > t.y) + (x.z > 0.0f && x.z > t.z) + (x.w > 0.0f && x.w > t.w);
         }
     } else {
-        for (int i = threadIdx.x; i < F; i += LTPB) c += list_entry(xr[i], th, i);
+        for (int i = s0 + lane; i < s1; i += 64) c += list_entry(xr[i], th, i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    if (lane == 0) { sh[w] = c; if (wave_cnt) wave_cnt[(long)blockIdx.x * 4 + w] = c; }
     __syncthreads();
     if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
@@ -162,7 +174,8 @@ static inline void launch_scan(const uint32_t* cnt, int n, uint32_t* start, uint
 // ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row
 __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
                                                         const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
-                                                        float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow, const int32_t* __restrict__ gate, int gate_on) {
+                                                        float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow, const int32_t* __restrict__ gate, int gate_on,
+                                                        const uint32_t* __restrict__ wave_cnt = nullptr) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     __shared__ uint32_t wcnt[4];
     const long row = blockIdx.x;
@@ -170,11 +183,13 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* th = theta ? theta + (row % L) * F : nullptr;
     const int colbase = (int)(row % L) * F;
-    if (F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0) {
-        // 16-byte loads, a wave owns a quarter of the row (a multiple of 256 columns): count its entries, then place them in
-        // column order — lane l's four consecutive columns before lane l + 1's (four ballots give the offsets).  The second
-        // sweep finds the row in L2.  (The scalar form below read the row twice, 4 bytes per lane: 4.9 ms for 6.4 GB.)
-        const int seg = (F / 4 + 255) / 256 * 256;
+    const bool vec = rows_vec_form(xr, th, F);
+    if (vec) {
+        // 16-byte loads, a wave owns a quarter of the row (a multiple of 256 columns): its entries are placed in column
+        // order — lane l's four consecutive columns before lane l + 1's (four ballots give the offsets) — behind the entries
+        // of the waves before it, whose counts count_rows_kernel left in wave_cnt (without them: one counting sweep first).
+        // (The scalar form below read the row twice, 4 bytes per lane: 4.9 ms for 6.4 GB.)
+        const int seg = rows_seg(F, true);
         const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
         auto flags = [&](int i, bool in, float4& x, bool p[4]) {
             const int ii = in ? i : 0;                     // (column 0 is always readable; F % 4 == 0, so i + 3 < F when in)
@@ -184,19 +199,23 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
             p[0] = in && x.x > 0.0f && x.x > t.x; p[1] = in && x.y > 0.0f && x.y > t.y;
             p[2] = in && x.z > 0.0f && x.z > t.z; p[3] = in && x.w > 0.0f && x.w > t.w;
         };
-        uint32_t c = 0;
-        for (int base = s0; base < s1; base += 256) {
-            const int i = base + lane * 4;
-            float4 x; bool p[4];
-            flags(i, i < s1, x, p);
-            c += (uint32_t)p[0] + (uint32_t)p[1] + (uint32_t)p[2] + (uint32_t)p[3];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0) wcnt[w] = c;
-        __syncthreads();
         uint32_t off = row_start[row];
-        for (int k = 0; k < w; ++k) off += wcnt[k];
+        if (wave_cnt) {
+            for (int k = 0; k < w; ++k) off += wave_cnt[row * 4 + k];
+        } else {
+            uint32_t c = 0;
+            for (int base = s0; base < s1; base += 256) {
+                const int i = base + lane * 4;
+                float4 x; bool p[4];
+                flags(i, i < s1, x, p);
+                c += (uint32_t)p[0] + (uint32_t)p[1] + (uint32_t)p[2] + (uint32_t)p[3];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0) wcnt[w] = c;
+            __syncthreads();
+            for (int k = 0; k < w; ++k) off += wcnt[k];
+        }
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int base = s0; base < s1; base += 256) {
             const int i = base + lane * 4;

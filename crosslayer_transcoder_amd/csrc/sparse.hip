@@ -380,19 +380,21 @@ int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t c
     uint32_t* cursor = col_cnt + ncols;
     int32_t* long_list = (int32_t*)(cursor + ncols);
     uint32_t* long_count = (uint32_t*)(long_list + ncols);
+    uint32_t* wave_cnt = long_count + 64;                  // [rows][4]: per-wave entry counts, count_rows -> fill_rows
     if (!gate) {            // the gated caller clears these itself (a memset cannot be gated)
         if (hipMemsetAsync(col_cnt, 0, (size_t)2 * ncols * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1);
+    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1);
     if (own_gate) {         // (threshold lists: the remaining kernels exit at once when the count exceeds cap)
         int32_t* gw = (int32_t*)(long_count + 8);
         hipLaunchKernelGGL(list_gate_kernel, dim3(1), dim3(1), 0, st, total, cap, gw, overflow);
         gate = gw;
     }
-    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, overflow, gate, 1);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, overflow, gate, 1,
+                       (const uint32_t*)wave_cnt);
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
     launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
@@ -408,7 +410,7 @@ extern "C" {
 
 size_t clt_sparse_build_workspace_bytes(int B, int L, int F) {
     const size_t rows = (size_t)B * L, ncols = (size_t)L * F;
-    return (rows + 3 * ncols + 64) * sizeof(uint32_t);
+    return (5 * rows + 3 * ncols + 64) * sizeof(uint32_t);
 }
 
 int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
