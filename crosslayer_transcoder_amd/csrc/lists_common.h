@@ -13,34 +13,47 @@ constexpr int LTPB = 256;
 // well: the lists of JumpReLU(feat) straight from the pre-activations (jumprelu.py:33-37: x * [(x > theta) & (x > 0)]).
 __device__ __forceinline__ bool list_entry(float x, const float* __restrict__ th, int col) { return x > 0.0f && (!th || x > th[col]); }
 
+// Element type of the dense tensor the lists are built from: XT = 0 fp32, 1 bf16, 2 fp16 (the dense 16-bit regime's
+// pre-activations, clt_gemm_bf16_nt_out16); entries are stored widened to fp32 either way.
+template <int XT> __device__ __forceinline__ float4 rows_ld4(const void* __restrict__ xr, int i) {
+    if (XT == 0) return *reinterpret_cast<const float4*>(static_cast<const float*>(xr) + i);
+    const ushort4 h = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(xr) + i);
+    return make_float4(cvt16<XT == 2>(h.x), cvt16<XT == 2>(h.y), cvt16<XT == 2>(h.z), cvt16<XT == 2>(h.w));
+}
+template <int XT> __device__ __forceinline__ float rows_ld1(const void* __restrict__ xr, int i) {
+    if (XT == 0) return static_cast<const float*>(xr)[i];
+    return cvt16<XT == 2>(static_cast<const uint16_t*>(xr)[i]);
+}
 // Segment of the row that wave w of the block owns, for both list-build kernels: a quarter of the row, whole 16-byte groups of
 // 64 lanes in the vector form.  wave_cnt (optional, [rows][4]): the per-wave counts, so that fill_rows_kernel need not count again.
-__device__ __forceinline__ bool rows_vec_form(const float* xr, const float* th, int F) {
-    return F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & 15) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0;
+__device__ __forceinline__ bool rows_vec_form(const void* xr, const float* th, int F, int xbytes) {
+    return F % 4 == 0 && (reinterpret_cast<uintptr_t>(xr) & (uintptr_t)(4 * xbytes - 1)) == 0 && (reinterpret_cast<uintptr_t>(th) & 15) == 0;
 }
 __device__ __forceinline__ int rows_seg(int F, bool vec) { return vec ? (F / 4 + 255) / 256 * 256 : ((F + 3) / 4 + 63) / 64 * 64; }
 
-__global__ __launch_bounds__(LTPB) void count_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
+template <int XT = 0>
+__global__ __launch_bounds__(LTPB) void count_rows_kernel(const void* __restrict__ feat, int F, int L, const float* __restrict__ theta,
                                                          uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on,
                                                          uint32_t* __restrict__ wave_cnt = nullptr) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     __shared__ uint32_t sh[4];
-    const float* xr = feat + (long)blockIdx.x * F;
+    constexpr int XB = XT == 0 ? 4 : 2;
+    const void* xr = static_cast<const char*>(feat) + (long)blockIdx.x * F * XB;
     const float* th = theta ? theta + (long)(blockIdx.x % L) * F : nullptr;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool vec = rows_vec_form(xr, th, F);
+    const bool vec = rows_vec_form(xr, th, F, XB);
     const int seg = rows_seg(F, vec);
     const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
     uint32_t c = 0;
     if (vec) {                                             // 16-byte loads: the pass is a plain HBM stream
         for (int i = s0 + lane * 4; i < s1; i += 256) {
-            const float4 x = *reinterpret_cast<const float4*>(xr + i);
+            const float4 x = rows_ld4<XT>(xr, i);
             float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (th) t = *reinterpret_cast<const float4*>(th + i);
             c += (x.x > 0.0f && x.x > t.x) + (x.y > 0.0f && x.y > t.y) + (x.z > 0.0f && x.z > t.z) + (x.w > 0.0f && x.w > t.w);
         }
     } else {
-        for (int i = s0 + lane; i < s1; i += 64) c += list_entry(xr[i], th, i);
+        for (int i = s0 + lane; i < s1; i += 64) c += list_entry(rows_ld1<XT>(xr, i), th, i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
@@ -172,18 +185,20 @@ static inline void launch_scan(const uint32_t* cnt, int n, uint32_t* start, uint
 }
 
 // ordered compaction of the positive entries of each row; wave w owns a contiguous quarter of the row
-__global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict__ feat, int F, int L, const float* __restrict__ theta,
+template <int XT = 0>
+__global__ __launch_bounds__(LTPB) void fill_rows_kernel(const void* __restrict__ feat, int F, int L, const float* __restrict__ theta,
                                                         const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
                                                         float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow, const int32_t* __restrict__ gate, int gate_on,
                                                         const uint32_t* __restrict__ wave_cnt = nullptr) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     __shared__ uint32_t wcnt[4];
     const long row = blockIdx.x;
-    const float* xr = feat + row * F;
+    constexpr int XB = XT == 0 ? 4 : 2;
+    const void* xr = static_cast<const char*>(feat) + row * F * XB;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* th = theta ? theta + (row % L) * F : nullptr;
     const int colbase = (int)(row % L) * F;
-    const bool vec = rows_vec_form(xr, th, F);
+    const bool vec = rows_vec_form(xr, th, F, XB);
     if (vec) {
         // 16-byte loads, a wave owns a quarter of the row (a multiple of 256 columns): its entries are placed in column
         // order — lane l's four consecutive columns before lane l + 1's (four ballots give the offsets) — behind the entries
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
         const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
         auto flags = [&](int i, bool in, float4& x, bool p[4]) {
             const int ii = in ? i : 0;                     // (column 0 is always readable; F % 4 == 0, so i + 3 < F when in)
-            x = *reinterpret_cast<const float4*>(xr + ii);
+            x = rows_ld4<XT>(xr, ii);
             float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (th) t = *reinterpret_cast<const float4*>(th + ii);
             p[0] = in && x.x > 0.0f && x.x > t.x; p[1] = in && x.y > 0.0f && x.y > t.y;
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     const int seg = ((F + 3) / 4 + 63) / 64 * 64;
     const int s0 = w * seg, s1 = min(F, s0 + seg);
     uint32_t c = 0;
-    for (int i = s0 + lane; i < s1; i += 64) c += list_entry(xr[i], th, i);
+    for (int i = s0 + lane; i < s1; i += 64) c += list_entry(rows_ld1<XT>(xr, i), th, i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) wcnt[w] = c;
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(LTPB) void fill_rows_kernel(const float* __restrict
     for (int k = 0; k < w; ++k) off += wcnt[k];
     for (int base = s0; base < s1; base += 64) {
         const int i = base + lane;
-        const float v = i < s1 ? xr[i] : 0.0f;
+        const float v = i < s1 ? rows_ld1<XT>(xr, i) : 0.0f;
         const bool p = i < s1 && list_entry(v, th, i);
         const unsigned long long m = __ballot(p);
         if (p) {

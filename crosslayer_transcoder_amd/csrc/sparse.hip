@@ -366,10 +366,11 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_sparse)
 
 // workspace layout: row_cnt[rows] | col_cnt[ncols] | cursor[ncols] | long_list[ncols] | long_count
 // gate: NULL = always; otherwise every kernel runs only when *gate != 0 (the fallback of clt_select_lists_f32).
-int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
+int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
-                              const int32_t* gate, const float* theta, bool theta_gate) {
+                              const int32_t* gate, const float* theta, bool theta_gate, bool x16) {
+    const int xt = x16 ? (clt_host_state.fp16 ? 2 : 1) : 0;     // element type of feat: fp32 / bf16 / fp16
     if (B <= 0 || L <= 0 || F <= 0 || cap == 0) return CLT_ERR_SHAPE;
     if ((unsigned long long)L * F >= 0x7fffffffull || (unsigned long long)B * L >= 0x7fffffffull) return CLT_ERR_RANGE;
     if (!ws || wsb < clt_sparse_build_workspace_bytes(B, L, F)) return CLT_ERR_WORKSPACE;
@@ -386,15 +387,19 @@ int clt_internal_sparse_build(const float* feat, int B, int L, int F, uint32_t c
         if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(count_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
+    if (xt == 0) hipLaunchKernelGGL((count_rows_kernel<0>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
+    else if (xt == 1) hipLaunchKernelGGL((count_rows_kernel<1>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
+    else hipLaunchKernelGGL((count_rows_kernel<2>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1);
     if (own_gate) {         // (threshold lists: the remaining kernels exit at once when the count exceeds cap)
         int32_t* gw = (int32_t*)(long_count + 8);
         hipLaunchKernelGGL(list_gate_kernel, dim3(1), dim3(1), 0, st, total, cap, gw, overflow);
         gate = gw;
     }
-    hipLaunchKernelGGL(fill_rows_kernel, dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, overflow, gate, 1,
-                       (const uint32_t*)wave_cnt);
+#define FILL_ROWS(XT_) hipLaunchKernelGGL((fill_rows_kernel<XT_>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, \
+                                          overflow, gate, 1, (const uint32_t*)wave_cnt)
+    if (xt == 0) FILL_ROWS(0); else if (xt == 1) FILL_ROWS(1); else FILL_ROWS(2);
+#undef FILL_ROWS
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
     launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
@@ -426,6 +431,15 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
                                    void* stp) {
     return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
                                      total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true);
+}
+
+int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+                                   int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
+                                   int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb,
+                                   void* stp) {
+    if (F % 4 || (reinterpret_cast<uintptr_t>(x) & 7)) return CLT_ERR_ALIGN;
+    return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, true);
 }
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,

@@ -819,16 +819,19 @@ def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
 
 def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int) -> SparseLists:
     """Lists of JumpReLU(x) (theta [1, L, F]) or ReLU(x) (theta None) straight from the pre-activations x [B, L, F]:
-    entries = positions with x > theta and x > 0.  `overflow` (device int32 [1]) = 1 when more than `cap` entries exist
+    entries = positions with x > theta and x > 0 (x fp32, or 16-bit in the active operand format: values widened).  `overflow`
+    (device int32 [1]) = 1 when more than `cap` entries exist
     (the lists are then incomplete and the caller takes the dense regime); `total` holds the true count."""
-    _chk(x)
+    x16 = x.dtype in _DT16
+    _chk(x, x.dtype)
+    assert x.dtype == torch.float32 or (x.dtype == op16() and x.shape[-1] % 4 == 0)
     Bn, L, F = x.shape
     if theta is not None:
         _chk(theta)
         assert theta.numel() == L * F
     s = _empty_lists(Bn, L, F, int(cap), x.device)
     ws = workspace(lib.clt_sparse_build_workspace_bytes(Bn, L, F), x.device)
-    call("clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, Bn, L, F, s.cap,
+    call("clt_sparse_build_threshold_x16" if x16 else "clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, Bn, L, F, s.cap,
          s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
          s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
          ws.data_ptr(), ws.numel(), _stream())

@@ -273,6 +273,12 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
                                    size_t ws_bytes, void* stream);
+/* The same from 16-bit pre-activations (the active operand format: what clt_gemm_bf16_nt_out16 leaves — under the reference's
+ * autocast the encoder einsum returns a 16-bit tensor too); entry values are the widened 16-bit values.  F % 4 == 0. */
+int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+                                   int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
+                                   int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
+                                   size_t ws_bytes, void* stream);
 /* Selection straight to lists (replaces topk.py:58-61, 84-91, 117-128 + the list build above when the dense
  * feature tensor is not needed).  mode 0: k of F per (b,l) row (k <= 2048); 1: global k*B*L; 2: per layer k*B.
  * x: [B][L][F] fp32 pre-activations; col_mask (optional, uint8 [L*F]): positions with mask 0 count as -inf

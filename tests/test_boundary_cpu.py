@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.clt_arch() == b"gfx950" and _lib.lib.clt_abi_version() == _lib.ABI_VERSION
     # size queries are pure host code
     assert _lib.lib.clt_select_lists_workspace_bytes(4096, 12, 32768, 16, 1) > 0
-    assert _lib.lib.clt_sparse_build_workspace_bytes(16, 2, 32) == (32 + 3 * 64 + 64) * 4
+    assert _lib.lib.clt_sparse_build_workspace_bytes(16, 2, 32) == (5 * 32 + 3 * 64 + 64) * 4
 
 
 def _model(nl, dec="clt", L=2, d=110, F=32):
