@@ -120,6 +120,8 @@ COMPACT_AUX_GEMM_COLUMNS = os.environ.get("CLT_AUX_GEMM_COLS", "1") != "0"      
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
 #: dense bf16 JumpReLU regime: pre-activations / feature gradient stored as bf16 (CLT_DENSE_BF16_ACT=0: fp32, for A/B runs)
 DENSE_BF16_ACTIVATIONS = os.environ.get("CLT_DENSE_BF16_ACT", "1") != "0"
+#: ... and in the steps that build activation lists from them (CLT_LIST_BF16_ACT=0: fp32 pre-activations there, for A/B runs)
+LIST_BF16_ACTIVATIONS = os.environ.get("CLT_LIST_BF16_ACT", "1") != "0"
 FUSE_DENSE_JUMPRELU = True
 #: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
 FUSE_WEIGHT_PREP = True
@@ -604,10 +606,11 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 drift[:nseg] = 0.1
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
-    # dense bf16 regime with no list attempt this step: the pre-activations (and later the feature gradient) leave their
-    # GEMMs as bf16 — the K = d_acts GEMMs are bound by their epilogue stores, and the consumers read half the bytes
-    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None
-                 and not (sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0)))
+    # 16-bit regime of the JumpReLU module: the pre-activations (and later the feature gradient) leave their GEMMs as bf16 —
+    # the K = d_acts GEMMs are bound by their epilogue stores, and the consumers (tile passes; the list build when a list
+    # attempt is made this step, clt_sparse_build_threshold_x16) read half the bytes
+    attempt = bool(sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0))
+    act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None and (not attempt or (LIST_BF16_ACTIVATIONS and F % 4 == 0)))
     if S is None:
         pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), enc.b) if act16 else None
         if pre is None:

@@ -33,24 +33,29 @@ Tensor = torch.Tensor
 # dense-contraction operand passes through _q().  None = exact fp32/fp64 restatement of the reference.
 _OPERAND_DTYPE = None
 _GRAD_SCALE = 1.0
+_ROUND_PRE = False
 
 
 class operand_rounding:
     """with operand_rounding(torch.bfloat16): ...  — round GEMM operands as the 16-bit MFMA path does.
     grad_scale (fp16 mode, `precision: "16-mixed"`): gradient operands are rounded while multiplied by the loss scale, as
     they are under torch.amp.GradScaler (scale the loss, backward in fp16, unscale the fp32 gradients); an overflow shows
-    as inf / NaN in the gradients, which the caller treats as a skipped step."""
+    as inf / NaN in the gradients, which the caller treats as a skipped step.
+    round_pre: the encoder's pre-activations are rounded to the operand format as well — what the reference's autocast does
+    (under torch.autocast the encoder einsum, model/clt.py:157-165, RETURNS a 16-bit tensor; the sparsifier thresholds those
+    values).  Off: the build's fp32-accumulator pre-activations (selection modes, fp32 list regime)."""
 
-    def __init__(self, dtype, grad_scale: float = 1.0):
-        self.dtype, self.grad_scale = dtype, float(grad_scale)
+    def __init__(self, dtype, grad_scale: float = 1.0, round_pre: bool = False):
+        self.dtype, self.grad_scale, self.round_pre = dtype, float(grad_scale), bool(round_pre)
 
     def __enter__(self):
-        global _OPERAND_DTYPE, _GRAD_SCALE
-        self.old, _OPERAND_DTYPE, _GRAD_SCALE = (_OPERAND_DTYPE, _GRAD_SCALE), self.dtype, self.grad_scale
+        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE
+        self.old = (_OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE)
+        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE = self.dtype, self.grad_scale, self.round_pre
 
     def __exit__(self, *a):
-        global _OPERAND_DTYPE, _GRAD_SCALE
-        _OPERAND_DTYPE, _GRAD_SCALE = self.old
+        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE
+        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE = self.old
 
 
 def _q(t: Tensor) -> Tensor:
@@ -99,7 +104,7 @@ def encoder_fwd(xs: Tensor, W: Tensor, b: Tensor) -> Tensor:
     pre = torch.empty(B, L, W.shape[2], dtype=xs.dtype)
     for l in range(L):
         pre[:, l] = _q(xs[:, l]) @ _q(W[l]) + b[l]
-    return pre
+    return _q(pre) if _ROUND_PRE else pre
 
 
 def encoder_fwd_layer(x: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
