@@ -356,6 +356,8 @@ def main():
                    "fused_select_steps": stats.get("fused_select_steps", 0), "select_fallbacks": stats.get("select_fallbacks", 0),
                    "select_drift": (lambda t: None if t is None else [round(float(v), 5) for v in t[: t.numel() // 2].tolist()])(
                        getattr(mod.model.nonlinearity, "_kth_drift", None)),
+                   "list_density": (lambda S: None if S is None else round(float(S.total) / (args.batch * L * (F // max(world, 1))), 6))(
+                       mod.last_step.get("lists")),
                    "loss": float(mod.last_step["loss"])},
     }
     if rank == 0:
