@@ -79,6 +79,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// squared length of four consecutive row elements in ONE fixed operation order: shared by row_sqnorm_kernel and the
+// row norms the Adam row pass leaves behind (row_pass_kernel's sq_out), so that both give the same bits for a row
+__device__ __forceinline__ float sq4(float x, float y, float z, float w) {
+    return __fmaf_rn(w, w, __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

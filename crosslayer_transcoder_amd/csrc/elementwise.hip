@@ -338,10 +338,10 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ W, int rows, int d, 
     if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {          // 16-byte loads (rows stay 16-byte aligned)
         for (int j = lane * 4; j < d; j += 256) {
             const float4 v = *reinterpret_cast<const float4*>(p + j);
-            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            s += sq4(v.x, v.y, v.z, v.w);
         }
     } else {
-        for (int j = lane; j < d; j += 64) { const float v = p[j]; s += v * v; }
+        for (int j = lane; j < d; j += 64) { const float v = p[j]; s = __fmaf_rn(v, v, s); }
     }
     s = wave_sum(s);
     if (lane == 0) sq[row] = accumulate ? sq[row] + s : s;
@@ -940,7 +940,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 8; }
+int clt_abi_version(void) { return 9; }
 
 int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
     if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;

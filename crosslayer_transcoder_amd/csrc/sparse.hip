@@ -125,6 +125,9 @@ struct RowPassArgs {
     // optional per-row term: grad[r,:] += (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:] — the gradient that reaches a decoder
     // row through dec_norms (clt_lightning.py:438-448; same term as clt_adam_f32's row_dnorm / row_sq)
     const float* row_dnorm; const float* row_sq;
+    // optional (one wave per row, i.e. d <= 1024): squared length of the UPDATED row r to sq_out[r] — next step's dec_norms
+    // without another read of the matrix; same per-lane order and wave reduction as row_sqnorm_kernel
+    float* sq_out;
 };
 
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
@@ -142,7 +145,9 @@ __device__ __forceinline__ void rp_acc4(float* __restrict__ g4, float& dot, floa
     g4[0] = fmaf(cv, s.x, g4[0]); g4[1] = fmaf(cv, s.y, g4[1]); g4[2] = fmaf(cv, s.z, g4[2]); g4[3] = fmaf(cv, s.w, g4[3]);
     dot = fmaf(s.x, w4[0], dot); dot = fmaf(s.y, w4[1], dot); dot = fmaf(s.z, w4[2], dot); dot = fmaf(s.w, w4[3], dot);
 }
-template <int NT, bool VEC, int CW, bool F16>
+// SQ: also write the updated row's squared length (a.sq_out) — its own instantiation: compiled into the common kernel the
+// few extra instructions cost the headline launch 20 us (830 -> 851, register allocation of the whole body moved)
+template <int NT, bool VEC, int CW, bool F16, bool SQ = false>
 __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r) {
     constexpr int W = VEC ? 4 : 1;
     __shared__ float shdot[2][CW];
@@ -305,12 +310,14 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
     // loss scaling (clt_set_loss_scaling): the gathered sources carry the loss scale, the gradient is unscaled here; a step
     // whose gradients overflowed leaves weights, moments and shadow untouched (the dots and column sums above are still
     // written: the later passes of this step run, and skip likewise)
-    if (clt_skip_update()) return;
+    bool skip = false;
+    if constexpr (SQ) skip = clt_skip_update();     // (the row's length is still written: of the unchanged row)
+    else if (clt_skip_update()) return;
     const float unscale = clt_dev_state.grad_unscale;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int o = cb + (t * 64 + lane) * W;
-        if (o >= a.d) continue;
+        if (o >= a.d || skip) continue;
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             float gg = g[t][c] * unscale, pp = wv[t][c];
@@ -330,11 +337,21 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
             if (a.shadow) a.shadow[ro + o] = (uint16_t)pack16<F16>(wv[t][0], 0.0f);
         }
     }
+    if constexpr (SQ && CW == 1) if (a.sq_out) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (t * 64 + lane) * W;
+            if (o < a.d) s = VEC ? s + sq4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]) : __fmaf_rn(wv[t][0], wv[t][0], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) a.sq_out[r] = s;
+    }
 }
 
-template <int NT, bool VEC, int CW, bool F16 = false>
+template <int NT, bool VEC, int CW, bool F16 = false, bool SQ = false>
 __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
-    row_pass_body<NT, VEC, CW, F16>(a, CW == 1 ? blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
+    row_pass_body<NT, VEC, CW, F16, SQ>(a, CW == 1 ? blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
 }
 
 // Several weight matrices in ONE launch (clt_sparse_row_pass_group_f32): the rows of the matrices are laid end to end over
@@ -531,16 +548,17 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double lr,
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
                             const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
-                            const float* row_sq, void* stp) {
+                            const float* row_sq, float* sq_out, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
+    if (sq_out && (grad_out || d > 1024)) return CLT_ERR_SHAPE;   // the updated row's norm: Adam form, one wave per row
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
-    RowPassArgs a;
+    RowPassArgs a = {};
     a.W = W; a.m = m; a.v = v; a.shadow = shadow; a.grad_out = grad_out; a.rows = rows; a.d = d; a.F = F; a.col0 = col0;
     a.src_bf16 = src_bf16;
     if (extra && !extra_map) return CLT_ERR_SHAPE;
     a.extra = extra; a.extra_map = extra_map; a.extra_colsum = extra ? extra_colsum : nullptr;
-    a.row_dnorm = row_dnorm; a.row_sq = row_sq;
+    a.row_dnorm = row_dnorm; a.row_sq = row_sq; a.sq_out = sq_out;
     a.src_layer = src_layer; a.L = L; a.col_start = col_start; a.tok = tok; a.coef = coef; a.src = src;
     a.col_start2 = col_start2; a.tok2 = tok2; a.coef2 = coef2; a.src2 = src2; a.dot_out = dot_out; a.dot_out2 = dot_out2; a.dot_stride = dot_stride; a.dot_stride2 = dot_stride2;
     a.dot_slot_base = dot_slot; a.colsum_out = colsum_out;
@@ -556,7 +574,10 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     const dim3 g4((rows + 3) / 4), g1(rows);
 #define RP(NT_, VEC_, CW_, GRID_)                                                                                          \
     do {                                                                                                                    \
-        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_, true>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a); \
+        if (CW_ == 1 && sq_out) {                                                                                           \
+            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, 1, true, true>), GRID_, dim3(TPB), 0, st, a); \
+            else hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, 1, false, true>), GRID_, dim3(TPB), 0, st, a);              \
+        } else if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_, true>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a); \
         else hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a);       \
     } while (0)
     if (vec) {

@@ -139,6 +139,9 @@ PIPELINE_EXCHANGE = True
 #: Measured (scripts/gpu_breakeven.sh, B = 4096, F = 32768, bf16): list step = 14.9 ms + 2.4 ms per 0.1 % active (PLT) /
 #: 37.4 + 11.4 (CLT) against 19.8 / 61.5 ms dense: both cross at ~0.2 % active, i.e. L0 ~ 65 features per token and layer.
 LIST_MAX_DENSITY = 1.0 / 512
+#: list regime with the fused optimizer: the Adam row passes write each updated decoder row's squared length, which is
+#: the next step's dec_norms (CLT at G32: 78 row_sqnorm launches = 1.36 ms of 34.8 per step otherwise)
+ROW_PASS_KEEPS_NORMS = os.environ.get("CLT_ROW_PASS_NORMS", "1") != "0"
 #: after a step whose density was above the break-even, the next attempt is made this many steps later (doubling, capped)
 LIST_RETRY_FIRST, LIST_RETRY_MAX = 8, 512
 
@@ -285,11 +288,21 @@ class _Decoder:
         else:
             grads["decoder.W"] = ops.plt_decoder_wgrad(feat, g, grads.get("decoder.W"), accumulate="decoder.W" in grads)
 
+    def _version_key(self):
+        return [(w._version, getattr(w, "_clt_version", 0), w.data_ptr(), ops.op16()) for w in self.W32]
+
     def sqnorms(self):
         if self._sq is not None:
             return self._sq
         F = self.dec.d_features
         sq = torch.zeros(self.L * F, dtype=torch.float32, device=self.W32[0].device)
+        kept = getattr(self.dec, "_row_sq_parts", None) if ROW_PASS_KEEPS_NORMS else None
+        if kept is not None and kept[0] == self._version_key():
+            # list regime: last step's fused Adam row passes left every updated row's squared length behind (same bits
+            # as row_sqnorm of the matrix); summed in the same ascending order, no read of the 7.85 GB of weights
+            for part in kept[1]:
+                sq[:part.numel()] += part
+            return sq
         for w in self.W32:                      # ascending l: the reference's accumulation order (:440-444)
             ops.row_sqnorm(w, sq, 0, True)
         return sq
@@ -335,15 +348,23 @@ class _Decoder:
         gradient through dec_norms (`row_term` = (dnorm, sq)) added per row, Adam in place when `fused`."""
         if self.bf16:
             g = g16 if g16 is not None else ops.cast_bf16(g)
+        keep = ROW_PASS_KEEPS_NORMS and fused is not None and self.dec.d_acts <= 1024
+        parts = []
+        self.dec._row_sq_parts = None
         for l, (name, w) in enumerate(zip(self.names(), self.W32)):
             kw = dict(row_term=row_term)
             if fused is not None:
                 kw.update(fused.begin_fused(w))
                 if self.shadow:
                     kw["shadow"] = self.shadows()[l]
+                if keep:
+                    parts.append(torch.empty(w.numel() // w.shape[-1], dtype=torch.float32, device=w.device))
+                    kw["sq_out"] = parts[-1]
             else:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
             ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+        if keep:                                # valid while nothing else changes the weights (same key as the shadows)
+            self.dec._row_sq_parts = (self._version_key(), parts)
 
     def sparse_bwd(self, S, g, S2, g2, grads, fused, extra=None, g16=None, slabs=None, groups=None):
         """Row pass over every decoder weight row: dW (or in-place Adam) + d(loss)/d(feature) per list entry.

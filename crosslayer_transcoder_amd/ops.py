@@ -1149,15 +1149,19 @@ def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
                     shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None, row_term=None,
-                    src_slab=False):
+                    src_slab=False, sq_out=None):
     """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
     per-entry dots go to `dots2` ([slots, lists2.cap]).  `extra` = (compact gradient [n, d] fp32, map int32 [L*F],
     compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows.
     `row_term` = (dnorm [L*F], sq [L*F]): adds (dnorm[col] / sqrt(sq[col])) * W[row] to the row's gradient.
-    `src_slab`: `src` is ONE layer's slab [B, d] (layer `src_layer` of a layer-major source) instead of [B, L, d]."""
+    `src_slab`: `src` is ONE layer's slab [B, d] (layer `src_layer` of a layer-major source) instead of [B, L, d].
+    `sq_out` ([rows] fp32; Adam form, d <= 1024): squared length of every UPDATED row (= row_sqnorm of the new matrix)."""
     _chk(W); _chk(coef)
+    if sq_out is not None:
+        _chk(sq_out)
+        assert grad_out is None and W.shape[-1] <= 1024 and sq_out.numel() >= W.numel() // W.shape[-1]
     rdn, rsq = row_term if row_term is not None else (None, None)
     if rdn is not None:
         _chk(rdn); _chk(rsq)
@@ -1186,7 +1190,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), _stream())
+         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), ptr(sq_out), _stream())
 
 
 def sparse_row_pass_group(Ws, s: SparseLists, coef, srcs, layers, *, adam, ms, vs, shadows=None, dots=None, src_slab=False) -> bool:

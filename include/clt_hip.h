@@ -394,7 +394,10 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  * extra (optional, with extra_map): a dense gradient contribution for a subset of the rows — the compacted TopK-aux
  * pass below —: grad[r,:] += extra[extra_map[col0 + r]][0:d] and colsum_out[col] += extra_colsum[extra_map[col]]
  * wherever extra_map[...] >= 0.  row_dnorm / row_sq (optional, [L*F], indexed by column): grad[r,:] +=
- * (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:], the gradient through dec_norms (clt_lightning.py:438-448). */
+ * (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:], the gradient through dec_norms (clt_lightning.py:438-448).
+ * sq_out (optional, [rows]; Adam form and d <= 1024 only, CLT_ERR_SHAPE otherwise): sq_out[r] = |W[r,:]|^2 of the
+ * UPDATED row, bit-identical to clt_row_sqnorm_f32 on the updated matrix — the next step's dec_norms
+ * (clt_lightning.py:440-444) without another read of the weights. */
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
@@ -402,7 +405,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
                             const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
-                            void* stream);
+                            float* sq_out, void* stream);
 /* Several weight matrices of one decoder in ONE launch of the same pass (Adam in place; no gradient output, second list,
  * compact contribution or row term): matrix i has rows[i] rows of d floats (row r <-> CSC column r), gathers from src[i]
  * (a [B][L][d] tensor, layer src_layer[i]; fp32, or 16-bit when src_bf16) and writes its dots to slot

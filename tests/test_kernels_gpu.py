@@ -641,6 +641,37 @@ def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16):
     assert not torch.equal(res[0][0][L - 1], _rand(L, F, d, seed=20 + L - 1, scale=0.05).to(DEV))     # (the pass did move the weights)
 
 
+@pytest.mark.parametrize("d,bf16", [(40, True), (768, True), (70, False), (1024, False)])
+def test_sparse_row_pass_leaves_updated_row_norms(ops, d, bf16):
+    """sq_out of clt_sparse_row_pass_f32 = clt_row_sqnorm_f32 of the UPDATED matrix, bit for bit (one shared operation order),
+    and asking for it leaves the update what it was (to fp32 rounding: the kernel with the extra output is its own
+    instantiation).  A matrix with d > 1024 (several waves per row) refuses it."""
+    B, L, F = 37, 3, 96
+    feat = _sparse_features(B, L, F, 6, seed=3)
+    S = ops.sparse_build(feat.to(DEV), 6 * B * L)
+    g = _rand(B, L, d, seed=5).to(DEV)
+    src = ops.cast_bf16(g) if bf16 else g
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, adamw=False, step=3)
+    dn, sq_in = _rand(L * F, seed=8).to(DEV), (_rand(L * F, seed=9).abs() + 0.1).to(DEV)
+    res = []
+    for keep in (False, True):
+        W, m = _rand(L, F, d, seed=20, scale=0.05).to(DEV), _rand(L, F, d, seed=30, scale=0.01).to(DEV)
+        v = _rand(L, F, d, seed=40, scale=0.01).to(DEV).abs()
+        sq_out = torch.full((L * F,), -1.0, device=DEV) if keep else None
+        ops.sparse_row_pass(W, S, S.csc_val, src, 0, L - 1, adam=hp, m=m, v=v, row_term=(dn, sq_in), sq_out=sq_out)
+        res.append((W, m, v, sq_out))
+    for x, y in zip(res[0][:3], res[1][:3]):       # (its own instantiation: fp32 contraction of the Adam arithmetic may differ)
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-9)
+    ref = torch.zeros(L * F, device=DEV)
+    ops.row_sqnorm(res[1][0], ref, 0, False)
+    assert torch.equal(res[1][3], ref)
+    assert torch.allclose(ref, res[1][0].double().pow(2).sum(-1).view(-1).float(), rtol=1e-5)
+    Wb = torch.zeros(2, 1028, device=DEV)
+    with pytest.raises(Exception):
+        ops.sparse_row_pass(Wb, S, S.csc_val, torch.zeros(B, L, 1028, device=DEV), 0, 0, adam=hp, m=torch.zeros_like(Wb),
+                            v=torch.zeros_like(Wb), sq_out=torch.zeros(2, device=DEV))
+
+
 @pytest.mark.parametrize("rows,L,F", [(64, 2, 256), (72, 3, 520)])
 def test_fused_dense_jumprelu_tile_passes_bf16_inputs(ops, rows, L, F):
     """The same tile passes fed with bf16 pre-activations / feature gradients (what clt_gemm_bf16_nt_out16 leaves) are the

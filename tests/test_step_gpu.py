@@ -465,6 +465,46 @@ def test_threshold_lists_bf16_step(dec_kind, nl_kind):
         assert rel < 1e-2, f"fused exp_avg {k}: rel l2 {rel:.3g}"
 
 
+@pytest.mark.parametrize("dec_kind", ["clt", "plt"])
+def test_threshold_lists_kept_row_norms_equal_recomputed(dec_kind, monkeypatch):
+    """List regime with Adam fused into the row pass: the squared row lengths the row passes leave behind
+    (engine.ROW_PASS_KEEPS_NORMS) are, bit for bit, clt_row_sqnorm_f32 of the updated matrices, so next step's dec_norms are
+    the ones a recomputation would give; an in-place change of a weight from outside moves the version key and drops them.
+    Three steps with and without: same losses (the two row-pass instantiations contract their fp32 Adam arithmetic
+    differently, so parameters agree to rounding, not bit for bit)."""
+    from crosslayer_transcoder_amd import engine, ops, precision
+    from tests.build_cases import build_module
+    case = _threshold_case(dec_kind, "jumprelu", 0.6)
+    batch = case["batches"][0].cuda()
+    res = []
+    for keep in (True, False):
+        monkeypatch.setattr(engine, "ROW_PASS_KEEPS_NORMS", keep)
+        mod = build_module(case)
+        mod.global_step, mod.log_metrics_every = 5, 0
+        opt, _ = mod.attach_optimizers()
+        losses = []
+        with precision("bf16-mixed"):
+            for i in range(3):
+                losses.append(float(mod.fused_train_step(batch, i, opt, sparse=True)))
+                dec = mod.model.decoder
+                kept = getattr(dec, "_row_sq_parts", None)
+                assert (kept is not None) == keep
+                if keep:
+                    D = engine._Decoder(dec)
+                    assert kept[0] == D._version_key()
+                    for w, part in zip(D.W32, kept[1]):
+                        ref = torch.zeros_like(part)
+                        ops.row_sqnorm(w, ref, 0, False)
+                        assert torch.equal(part, ref)
+                    if i == 1:                  # a change from outside: the kept norms are not used for the next step
+                        with torch.no_grad():
+                            D.W32[0].mul_(1.01)
+                        assert kept[0] != D._version_key()
+        res.append((losses, {k: p.detach().clone() for k, p in mod.model.named_parameters()}))
+    # (the keep=False run did not scale W32[0] after step 2: compare the first two losses only)
+    assert res[0][0][:2] == pytest.approx(res[1][0][:2], rel=1e-4)
+
+
 def test_threshold_list_gate_chooses_the_regime():
     """sparse=None on a JumpReLU module: the device-side count picks the list regime below the break-even density and the
     dense GEMM regime above it (then backs off: no attempt on the next steps); both give the same step (fp32 mode)."""
