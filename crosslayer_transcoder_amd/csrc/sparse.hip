@@ -22,6 +22,11 @@ constexpr int TPB = 256;
 // ------------------------------------------------------------------------------------------------
 // forward gather: one wave per (token, target layer)
 // ------------------------------------------------------------------------------------------------
+// FWD_U: gathered rows in flight per wave for d <= 768.  4, 8 and 16 measured the same (15.39 / 15.39 / 15.39 ms headline,
+// scripts/gpu_fwdu_ab.sh): the gather is not latency-bound at 4
+#ifndef FWD_U
+#define FWD_U 4
+#endif
 // F16: the 16-bit rows are fp16 instead of bf16 (clt_set_loss_scaling)
 template <int NT, bool VEC, bool BF, bool F16 = false>
 __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t* __restrict__ row_start, const int32_t* __restrict__ ent_col,
@@ -30,7 +35,7 @@ __global__ __launch_bounds__(TPB) void sparse_decoder_fwd_kernel(const uint32_t*
                                                                  int d, int cross_layer, uint32_t cap, long out_tok_stride,
                                                                  long out_layer_stride, int l_lo, int l_hi) {
     constexpr int W = VEC ? 4 : 1;
-    constexpr int U = NT <= 4 ? 4 : (NT <= 8 ? 2 : 1);         // entries in flight per wave (bounded by the register budget)
+    constexpr int U = NT <= 3 ? FWD_U : (NT <= 4 ? 4 : (NT <= 8 ? 2 : 1));   // entries in flight per wave (a divisor of 64; bounded by the register budget)
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // target layers are dealt to the 4 waves heaviest first in serpentine order (a cross-layer target l gathers the
     // entries of l + 1 source layers): 11,4,3 | 10,5,2 | 9,6,1 | 8,7,0 for L = 12
