@@ -62,6 +62,107 @@ __global__ __launch_bounds__(LTPB) void count_rows_kernel(const void* __restrict
     if (threadIdx.x == 0) row_cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Lists in the vector form, ROWS_PER_BLOCK rows of ONE layer per block (tokens b0 .. b0 + 3): four row loads in flight per
+// lane, and the layer's thresholds (TH) are read once for four rows.  With one row per block the fp32 thresholds re-read from L2 for every row are twice the bytes
+// of a 16-bit row: count + fill took 0.76 + 0.79 ms for 3.2 GB of pre-activations against 0.55 + 0.55 without thresholds
+// (scripts/build_probe.py).  Same per-wave segments, counts and entry order as count_rows_kernel / fill_rows_kernel.
+constexpr int ROWS_PER_BLOCK = 4;
+__device__ __forceinline__ uint32_t rows_hits(const float4 x, const float4 t) {
+    return (uint32_t)(x.x > 0.0f && x.x > t.x) + (uint32_t)(x.y > 0.0f && x.y > t.y) + (uint32_t)(x.z > 0.0f && x.z > t.z) +
+           (uint32_t)(x.w > 0.0f && x.w > t.w);
+}
+template <int XT, bool TH>
+__global__ __launch_bounds__(LTPB) void count_rows_th_kernel(const void* __restrict__ feat, int B, int F, int L, const float* __restrict__ theta,
+                                                            uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on,
+                                                            uint32_t* __restrict__ wave_cnt) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    constexpr int R = ROWS_PER_BLOCK, XB = XT == 0 ? 4 : 2;
+    __shared__ uint32_t sh[R][4];
+    const int l = blockIdx.x % L, b0 = (blockIdx.x / L) * R;
+    const int nb = min(R, B - b0);                         // >= 1 by the grid
+    const float* th = TH ? theta + (long)l * F : nullptr;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = rows_seg(F, true);
+    const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
+    const char* xr[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) xr[j] = static_cast<const char*>(feat) + ((long)(b0 + (j < nb ? j : 0)) * L + l) * F * XB;   // (rows past B: row b0 again, not counted)
+    uint32_t c[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) c[j] = 0;
+    for (int i = s0 + lane * 4; i < s1; i += 256) {
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (TH) t = *reinterpret_cast<const float4*>(th + i);
+        float4 x[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = rows_ld4<XT>(xr[j], i);
+#pragma unroll
+        for (int j = 0; j < R; ++j) c[j] += rows_hits(x[j], t);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c[j] += __shfl_xor(c[j], o, 64);
+        if (lane == 0 && j < nb) { sh[j][w] = c[j]; wave_cnt[((long)(b0 + j) * L + l) * 4 + w] = c[j]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) row_cnt[(long)(b0 + threadIdx.x) * L + l] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+template <int XT, bool TH>
+__global__ __launch_bounds__(LTPB) void fill_rows_th_kernel(const void* __restrict__ feat, int B, int F, int L, const float* __restrict__ theta,
+                                                           const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
+                                                           float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow,
+                                                           const int32_t* __restrict__ gate, int gate_on, const uint32_t* __restrict__ wave_cnt) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    constexpr int R = ROWS_PER_BLOCK, XB = XT == 0 ? 4 : 2;
+    const int l = blockIdx.x % L, b0 = (blockIdx.x / L) * R;
+    const int nb = min(R, B - b0);
+    const float* th = TH ? theta + (long)l * F : nullptr;
+    const int colbase = l * F;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = rows_seg(F, true);
+    const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
+    const char* xr[R];
+    uint32_t off[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const long row = (long)(b0 + (j < nb ? j : 0)) * L + l;
+        xr[j] = static_cast<const char*>(feat) + row * F * XB;
+        off[j] = row_start[row];
+        for (int k = 0; k < w; ++k) off[j] += wave_cnt[row * 4 + k];
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = s0; base < s1; base += 256) {
+        const int i = base + lane * 4;
+        const bool in = i < s1;
+        const int ii = in ? i : 0;                         // (column 0 is always readable; F % 4 == 0, so i + 3 < F when in)
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (TH) t = *reinterpret_cast<const float4*>(th + ii);
+        float4 x[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = rows_ld4<XT>(xr[j], ii);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j >= nb) continue;                         // (block-uniform)
+            const bool p[4] = {in && x[j].x > 0.0f && x[j].x > t.x, in && x[j].y > 0.0f && x[j].y > t.y,
+                               in && x[j].z > 0.0f && x[j].z > t.z, in && x[j].w > 0.0f && x[j].w > t.w};
+            const unsigned long long b0m = __ballot(p[0]), b1m = __ballot(p[1]), b2m = __ballot(p[2]), b3m = __ballot(p[3]);
+            if ((b0m | b1m | b2m | b3m) == 0ull) continue;
+            uint32_t pos = off[j] + (uint32_t)(__popcll(b0m & lt) + __popcll(b1m & lt) + __popcll(b2m & lt) + __popcll(b3m & lt));
+            const float xv[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p[q]) {
+                    if (pos < cap) { ent_col[pos] = colbase + i + q; ent_val[pos] = xv[q]; }
+                    else *overflow = 1;
+                    ++pos;
+                }
+            off[j] += (uint32_t)(__popcll(b0m) + __popcll(b1m) + __popcll(b2m) + __popcll(b3m));
+        }
+    }
+}
+
 // exclusive scan of cnt[0..n) into start[0..n], start[n] = total; single block of 1024 threads.  Per iteration the
 // block takes 16384 items as four 4096-item sub-chunks (thread t: 4 consecutive items of each, one 16-byte load when
 // aligned, so a wave reads 1 KB contiguous per load); the next iteration's loads are issued before this iteration's

@@ -459,6 +459,19 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
         if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
     }
+    // thresholds + vector form (every row has it when the bases are aligned and F % 4 == 0): four rows of a layer per block
+    const bool th4 = F % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & (uintptr_t)(xt == 0 ? 15 : 7)) == 0 &&
+                     (!theta || (reinterpret_cast<uintptr_t>(theta) & 15) == 0);
+    const dim3 g4((unsigned)(((B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * L));
+    if (th4) {
+#define COUNT_ROWS_TH(XT_)                                                                                                 \
+    do {                                                                                                                    \
+        if (theta) hipLaunchKernelGGL((count_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_cnt, gate, 1, wave_cnt); \
+        else hipLaunchKernelGGL((count_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_cnt, gate, 1, wave_cnt);    \
+    } while (0)
+        if (xt == 0) COUNT_ROWS_TH(0); else if (xt == 1) COUNT_ROWS_TH(1); else COUNT_ROWS_TH(2);
+#undef COUNT_ROWS_TH
+    } else
     if (xt == 0) hipLaunchKernelGGL((count_rows_kernel<0>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     else if (xt == 1) hipLaunchKernelGGL((count_rows_kernel<1>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     else hipLaunchKernelGGL((count_rows_kernel<2>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
@@ -470,8 +483,17 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
     }
 #define FILL_ROWS(XT_) hipLaunchKernelGGL((fill_rows_kernel<XT_>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, \
                                           overflow, gate, 1, (const uint32_t*)wave_cnt)
-    if (xt == 0) FILL_ROWS(0); else if (xt == 1) FILL_ROWS(1); else FILL_ROWS(2);
+#define FILL_ROWS_TH(XT_)                                                                                                  \
+    do {                                                                                                                    \
+        if (theta) hipLaunchKernelGGL((fill_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_start, ent_col, ent_val, \
+                                      cap, overflow, gate, 1, (const uint32_t*)wave_cnt);                                    \
+        else hipLaunchKernelGGL((fill_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_start, ent_col, ent_val,     \
+                                cap, overflow, gate, 1, (const uint32_t*)wave_cnt);                                          \
+    } while (0)
+    if (th4) { if (xt == 0) FILL_ROWS_TH(0); else if (xt == 1) FILL_ROWS_TH(1); else FILL_ROWS_TH(2); }
+    else if (xt == 0) FILL_ROWS(0); else if (xt == 1) FILL_ROWS(1); else FILL_ROWS(2);
 #undef FILL_ROWS
+#undef FILL_ROWS_TH
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
     launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,

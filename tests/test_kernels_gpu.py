@@ -405,6 +405,30 @@ def _lists_equal(A, Bl, what):
         assert torch.equal(getattr(A, name)[:n], getattr(Bl, name)[:n]), f"{what}: {name}"
 
 
+@pytest.mark.parametrize("x16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("B,L,F", [(37, 3, 264), (8, 2, 4096), (5, 1, 1028), (2, 4, 32768), (9, 2, 30)])
+def test_threshold_lists_equal_lists_of_the_thresholded_tensor(ops, B, L, F, x16):
+    """clt_sparse_build_threshold_* (JumpReLU lists straight from the pre-activations; with aligned operands four rows of a layer
+    per block, the layer's thresholds read once) == clt_sparse_build_f32 of x * [(x > theta) & (x > 0)] (jumprelu.py:36-37), bit
+    for bit, in every list array.  Token counts that are no multiple of four, rows shorter than a wave's segment, F % 4 != 0
+    (scalar form), 16-bit and fp32 pre-activations."""
+    g = torch.Generator().manual_seed(B * 7 + F)
+    x = torch.randn(B, L, F, generator=g) * 0.5
+    theta = torch.rand(1, L, F, generator=g) * 0.8
+    x = x.to(DEV)
+    if x16:
+        if F % 4:
+            pytest.skip("16-bit pre-activations need F % 4 == 0")
+        x = x.bfloat16()
+    theta = theta.to(DEV)
+    xf = x.float()
+    dense = xf * ((xf > theta) & (xf > 0))
+    cap = B * L * F
+    _lists_equal(ops.sparse_build_threshold(x, theta, cap), ops.sparse_build(dense, cap), "threshold lists")
+    relu = xf * (xf > 0)
+    _lists_equal(ops.sparse_build_threshold(x, None, cap), ops.sparse_build(relu, cap), "relu lists")
+
+
 @pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (16, 2, 32, 4), (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
                                      (2, 2, 64, 64), (512, 4, 8192, 16), (16, 2, 20000, 16), (8, 2, 12000, 100)])
 def test_select_lists_matches_dense_selection(ops, B, L, F, k):
