@@ -6,6 +6,8 @@ torch / CPU fallback — a non-CUDA tensor raises.
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -87,6 +89,19 @@ def _timed_raw(tag, payload, name, *args) -> int:
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+#: K-segmented feature-gradient GEMMs of a cross-layer decoder over two streams when their tile count leaves a short last
+#: round (see clt_decoder_dgrad_kseg); 1 = one stream
+KSEG_DGRAD_STREAMS = int(os.environ.get("CLT_KSEG_DGRAD_STREAMS", "2"))
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 
 
 def _chk(t: torch.Tensor, dtype=torch.float32, contiguous=True):
@@ -265,20 +280,39 @@ def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor], out_bf16: bo
         ptrs += [_chk(Ws[l], op16()).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
     table = torch.tensor(ptrs, dtype=torch.int64).to(g.device)
     df = torch.empty(Bn, L, F, dtype=op16() if out_bf16 else torch.float32, device=g.device)
+    # One persistent block per CU walks 256 x 256 tiles: a launch with a few tiles more than a multiple of 256 (the compacted
+    # TopK-aux pass: 16 x 18 = 288) spends a whole extra round on them.  The L launches write disjoint columns, so they
+    # alternate over two streams and one launch's short last round runs beside the next launch's first.
+    tiles = -(-Bn // 256) * -(-F // 256)
+    two = (KSEG_DGRAD_STREAMS > 1 and TIMING is None and L > 1 and tiles > 256 and 0 < tiles % 256 <= 128)
+    if two:
+        main, side = torch.cuda.current_stream(g.device), _side_stream(g.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
     off = 0
+    rc_bad = None
     for lp in range(L):
         nseg = L - lp
-        if out_bf16:
-            rc = _timed_raw("gemm", 2.0 * Bn * F * d * nseg, "clt_gemm_bf16_nt_kseg_out16", g.data_ptr() + 2 * lp * d,
-                            table.data_ptr() + 8 * off, df.data_ptr() + 2 * lp * F, Bn, F, nseg, d, L * d, d, L * F, _stream())
-        else:
-            rc = _timed_raw("gemm", 2.0 * Bn * F * d * nseg, "clt_gemm_bf16_nt_kseg", g.data_ptr() + 2 * lp * d, table.data_ptr() + 8 * off,
-                            df.data_ptr() + 4 * lp * F, Bn, F, nseg, d, L * d, d, L * F, None, 0, _stream())
-        if rc == 1:
-            return None
+        with torch.cuda.stream(side) if (two and lp % 2 == 1) else contextlib.nullcontext():
+            if out_bf16:
+                rc = _timed_raw("gemm", 2.0 * Bn * F * d * nseg, "clt_gemm_bf16_nt_kseg_out16", g.data_ptr() + 2 * lp * d,
+                                table.data_ptr() + 8 * off, df.data_ptr() + 2 * lp * F, Bn, F, nseg, d, L * d, d, L * F, _stream())
+            else:
+                rc = _timed_raw("gemm", 2.0 * Bn * F * d * nseg, "clt_gemm_bf16_nt_kseg", g.data_ptr() + 2 * lp * d, table.data_ptr() + 8 * off,
+                                df.data_ptr() + 4 * lp * F, Bn, F, nseg, d, L * d, d, L * F, None, 0, _stream())
         if rc != 0:
-            raise CltError("clt_gemm_bf16_nt_kseg", rc)
+            rc_bad = rc
+            break
         off += nseg
+    if two:                                    # (also on the error paths: nothing of this call may outlive it on the side stream)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        main.wait_event(ev)
+    if rc_bad == 1:
+        return None
+    if rc_bad is not None:
+        raise CltError("clt_gemm_bf16_nt_kseg", rc_bad)
     return df
 
 
