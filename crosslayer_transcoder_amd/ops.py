@@ -284,7 +284,7 @@ def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor], out_bf16: bo
     # TopK-aux pass: 16 x 18 = 288) spends a whole extra round on them.  The L launches write disjoint columns, so they
     # alternate over two streams and one launch's short last round runs beside the next launch's first.
     tiles = -(-Bn // 256) * -(-F // 256)
-    two = (KSEG_DGRAD_STREAMS > 1 and TIMING is None and L > 1 and tiles > 256 and 0 < tiles % 256 <= 128)
+    two = (KSEG_DGRAD_STREAMS > 1 and TIMING is None and L > 1 and 0 < tiles % 256 <= 128)      # (also: at most half the CUs busy)
     if two:
         main, side = torch.cuda.current_stream(g.device), _side_stream(g.device)
         ev = torch.cuda.Event()
