@@ -555,7 +555,7 @@ def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max())), nm
 
 
-def test_clt_dgrad_k_segmented_equals_accumulating_chain(ops):
+def test_clt_dgrad_k_segmented_equals_accumulating_chain(ops, monkeypatch):
     """clt_gemm_bf16_nt_kseg (feature gradient of the cross-layer decoder as one GEMM per source layer, K-segmented
     over the per-target-layer weight tensors) vs the chain of accumulating GEMMs and vs an fp64 reference."""
     B, L, d, F = 512, 3, 128, 512
@@ -572,6 +572,13 @@ def test_clt_dgrad_k_segmented_equals_accumulating_chain(ops):
         for lp in range(l + 1):
             want[:, lp] += gd[:, l] @ Wo[l][lp].double().cpu().T
     assert torch.allclose(df.double().cpu(), want, rtol=1e-4, atol=1e-3)
+    # this shape (2 tiles per launch) alternates its launches over two streams: same bits on one stream, fp32 and 16-bit results
+    for out16 in (False, True):
+        monkeypatch.setattr(ops, "KSEG_DGRAD_STREAMS", 2)
+        a2 = ops.clt_decoder_dgrad_kseg(go, Wo, out16)
+        monkeypatch.setattr(ops, "KSEG_DGRAD_STREAMS", 1)
+        a1 = ops.clt_decoder_dgrad_kseg(go, Wo, out16)
+        assert torch.equal(a1, a2) and (out16 or torch.equal(a1, df))
 
 
 def test_clt_decoder_fwd_grouped_launches(ops, monkeypatch):
