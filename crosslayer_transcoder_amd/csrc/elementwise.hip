@@ -885,10 +885,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         gg *= unscale;
         if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
-        mm = mm + (gg - mm) * omb1;
-        vv = vv * b2 + omb2 * gg * gg;
-        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-        pp -= step_size * (mm / denom);
+        // (explicit fused multiply-adds, the same sequence as the Adam inside row_pass_kernel: both regimes update alike)
+        mm = __fmaf_rn(gg - mm, omb1, mm);
+        vv = __fmaf_rn(vv, b2, (omb2 * gg) * gg);
+        const float denom = __fmaf_rn(sqrtf(vv), inv_sqrt_bc2, eps);
+        pp = __fmaf_rn(-step_size, mm / denom, pp);
     };
     const long stride = (long)gridDim.x * blockDim.x;
 #ifndef ADAM_VARIANT

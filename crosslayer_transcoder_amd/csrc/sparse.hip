@@ -150,6 +150,35 @@ __device__ __forceinline__ void rp_acc4(float* __restrict__ g4, float& dot, floa
     g4[0] = fmaf(cv, s.x, g4[0]); g4[1] = fmaf(cv, s.y, g4[1]); g4[2] = fmaf(cv, s.z, g4[2]); g4[3] = fmaf(cv, s.w, g4[3]);
     dot = fmaf(s.x, w4[0], dot); dot = fmaf(s.y, w4[1], dot); dot = fmaf(s.z, w4[2], dot); dot = fmaf(s.w, w4[3], dot);
 }
+// RP_NT (bit 0 loads, bit 1 stores): the weight / moment streams of the row pass (read once, written once per step) as
+// non-temporal accesses, so that they do not displace the gathered source rows ([B, L, d], 75 MB at G32 in bf16) from the
+// caches.  Headline launch 829 -> 815 us (loads) -> 812 us (loads + stores; stores alone 835), scripts/gpu_rpnt_ab.sh
+#ifndef RP_NT
+#define RP_NT 3
+#endif
+typedef float rp_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rp_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 rp_ld4(const float* q) {
+#if RP_NT & 1
+    const rp_f4 t = __builtin_nontemporal_load(reinterpret_cast<const rp_f4*>(q)); return make_float4(t[0], t[1], t[2], t[3]);
+#else
+    return *reinterpret_cast<const float4*>(q);
+#endif
+}
+__device__ __forceinline__ void rp_st4(float* q, float a, float b, float c, float d) {
+#if RP_NT & 2
+    const rp_f4 t = {a, b, c, d}; __builtin_nontemporal_store(t, reinterpret_cast<rp_f4*>(q));
+#else
+    *reinterpret_cast<float4*>(q) = make_float4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ void rp_st2(uint16_t* q, uint32_t a, uint32_t b) {
+#if RP_NT & 2
+    const rp_u2 t = {a, b}; __builtin_nontemporal_store(t, reinterpret_cast<rp_u2*>(q));
+#else
+    *reinterpret_cast<uint2*>(q) = make_uint2(a, b);
+#endif
+}
 // SQ: also write the updated row's squared length (a.sq_out) — its own instantiation: compiled into the common kernel the
 // few extra instructions cost the headline launch 20 us (830 -> 851, register allocation of the whole body moved)
 template <int NT, bool VEC, int CW, bool F16, bool SQ = false>
@@ -172,7 +201,7 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
 #pragma unroll
         for (int c = 0; c < W; ++c) { g[t][c] = 0.0f; wv[t][c] = 0.0f; }
         if (need_w && o < a.d) {
-            if (VEC) { const float4 x = *reinterpret_cast<const float4*>(a.W + ro + o); wv[t][0] = x.x; wv[t][1 % W] = x.y; wv[t][2 % W] = x.z; wv[t][3 % W] = x.w; }
+            if (VEC) { const float4 x = rp_ld4(a.W + ro + o); wv[t][0] = x.x; wv[t][1 % W] = x.y; wv[t][2 % W] = x.z; wv[t][3 % W] = x.w; }
             else wv[t][0] = a.W[ro + o];
         }
     }
@@ -186,8 +215,8 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
             for (int c = 0; c < W; ++c) { mm[t][c] = 0.0f; vv[t][c] = 0.0f; }
             if (o < a.d) {
                 if (VEC) {
-                    const float4 x = *reinterpret_cast<const float4*>(a.m + ro + o); mm[t][0] = x.x; mm[t][1 % W] = x.y; mm[t][2 % W] = x.z; mm[t][3 % W] = x.w;
-                    const float4 y = *reinterpret_cast<const float4*>(a.v + ro + o); vv[t][0] = y.x; vv[t][1 % W] = y.y; vv[t][2 % W] = y.z; vv[t][3 % W] = y.w;
+                    const float4 x = rp_ld4(a.m + ro + o); mm[t][0] = x.x; mm[t][1 % W] = x.y; mm[t][2 % W] = x.z; mm[t][3 % W] = x.w;
+                    const float4 y = rp_ld4(a.v + ro + o); vv[t][0] = y.x; vv[t][1 % W] = y.y; vv[t][2 % W] = y.z; vv[t][3 % W] = y.w;
                 } else { mm[t][0] = a.m[ro + o]; vv[t][0] = a.v[ro + o]; }
             }
         }
@@ -327,16 +356,18 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
         for (int c = 0; c < W; ++c) {
             float gg = g[t][c] * unscale, pp = wv[t][c];
             if (a.wd != 0.0f) { if (a.adamw) pp *= (1.0f - a.lr * a.wd); else gg += a.wd * pp; }
-            mm[t][c] = mm[t][c] + (gg - mm[t][c]) * a.omb1;
-            vv[t][c] = vv[t][c] * a.b2 + a.omb2 * gg * gg;
-            pp -= a.step_size * (mm[t][c] / (sqrtf(vv[t][c]) * a.isb2 + a.eps));
+            // (explicit fused multiply-adds: left to the compiler, the contraction of these lines differed between the
+            // instantiations of this body — 1 ulp in v and W between kernels that must agree bit for bit)
+            mm[t][c] = __fmaf_rn(gg - mm[t][c], a.omb1, mm[t][c]);
+            vv[t][c] = __fmaf_rn(vv[t][c], a.b2, (a.omb2 * gg) * gg);
+            pp = __fmaf_rn(-a.step_size, mm[t][c] / __fmaf_rn(sqrtf(vv[t][c]), a.isb2, a.eps), pp);
             wv[t][c] = pp;
         }
         if (VEC) {
-            *reinterpret_cast<float4*>(a.W + ro + o) = make_float4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
-            *reinterpret_cast<float4*>(a.m + ro + o) = make_float4(mm[t][0], mm[t][1 % W], mm[t][2 % W], mm[t][3 % W]);
-            *reinterpret_cast<float4*>(a.v + ro + o) = make_float4(vv[t][0], vv[t][1 % W], vv[t][2 % W], vv[t][3 % W]);
-            if (a.shadow) *reinterpret_cast<uint2*>(a.shadow + ro + o) = make_uint2(pack16<F16>(wv[t][0], wv[t][1 % W]), pack16<F16>(wv[t][2 % W], wv[t][3 % W]));
+            rp_st4(a.W + ro + o, wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
+            rp_st4(a.m + ro + o, mm[t][0], mm[t][1 % W], mm[t][2 % W], mm[t][3 % W]);
+            rp_st4(a.v + ro + o, vv[t][0], vv[t][1 % W], vv[t][2 % W], vv[t][3 % W]);
+            if (a.shadow) rp_st2(a.shadow + ro + o, pack16<F16>(wv[t][0], wv[t][1 % W]), pack16<F16>(wv[t][2 % W], wv[t][3 % W]));
         } else {
             a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[t][0]; a.v[ro + o] = vv[t][0];
             if (a.shadow) a.shadow[ro + o] = (uint16_t)pack16<F16>(wv[t][0], 0.0f);

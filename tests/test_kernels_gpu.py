@@ -675,8 +675,7 @@ def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16):
 @pytest.mark.parametrize("d,bf16", [(40, True), (768, True), (70, False), (1024, False)])
 def test_sparse_row_pass_leaves_updated_row_norms(ops, d, bf16):
     """sq_out of clt_sparse_row_pass_f32 = clt_row_sqnorm_f32 of the UPDATED matrix, bit for bit (one shared operation order),
-    and asking for it leaves the update what it was (to fp32 rounding: the kernel with the extra output is its own
-    instantiation).  A matrix with d > 1024 (several waves per row) refuses it."""
+    and asking for it leaves the update what it was, bit for bit (the kernel with the extra output is its own instantiation).  A matrix with d > 1024 (several waves per row) refuses it."""
     B, L, F = 37, 3, 96
     feat = _sparse_features(B, L, F, 6, seed=3)
     S = ops.sparse_build(feat.to(DEV), 6 * B * L)
@@ -691,8 +690,8 @@ def test_sparse_row_pass_leaves_updated_row_norms(ops, d, bf16):
         sq_out = torch.full((L * F,), -1.0, device=DEV) if keep else None
         ops.sparse_row_pass(W, S, S.csc_val, src, 0, L - 1, adam=hp, m=m, v=v, row_term=(dn, sq_in), sq_out=sq_out)
         res.append((W, m, v, sq_out))
-    for x, y in zip(res[0][:3], res[1][:3]):       # (its own instantiation: fp32 contraction of the Adam arithmetic may differ)
-        assert torch.allclose(x, y, rtol=1e-5, atol=1e-9)
+    for x, y in zip(res[0][:3], res[1][:3]):       # (its own instantiation; the Adam arithmetic is explicit FMAs, so: same bits)
+        assert torch.equal(x, y)
     ref = torch.zeros(L * F, device=DEV)
     ops.row_sqnorm(res[1][0], ref, 0, False)
     assert torch.equal(res[1][3], ref)
