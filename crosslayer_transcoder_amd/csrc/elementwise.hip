@@ -481,6 +481,23 @@ __device__ __forceinline__ void ft_store_pair(uint32_t (*tile)[FT_PITCH], int p,
     q[0] = make_uint2(pack16<F16>(a[0], b[0]), pack16<F16>(a[1], b[1]));
     q[1] = make_uint2(pack16<F16>(a[2], b[2]), pack16<F16>(a[3], b[3]));
 }
+// TILE_NT (bit 0 loads, bit 1 stores): the activation streams of the tile passes as non-temporal accesses.  Measured SLOWER
+// (PLT JumpReLU dense 19.9 ms -> 20.0 with loads, 20.4 with stores, scripts/gpu_tilent_ab.sh): what these passes write is the
+// next GEMM's operand and what they read the last GEMM's result, and part of it is still in the memory-side cache; unlike the
+// row pass's weight streams and the GEMMs' C tiles, where the hint pays.  Off.
+#ifndef TILE_NT
+#define TILE_NT 0
+#endif
+typedef unsigned int tp_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tp_u2 __attribute__((ext_vector_type(2)));
+typedef float tp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tp_st16(void* q, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if TILE_NT & 2
+    const tp_u4 t = {a, b, c, d}; __builtin_nontemporal_store(t, reinterpret_cast<tp_u4*>(q));
+#else
+    *reinterpret_cast<uint4*>(q) = make_uint4(a, b, c, d);
+#endif
+}
 // transposed write-out of a [64][256] bf16 tile: column c gets 64 consecutive rows (128 B); 8 threads x 16 B per column
 __device__ __forceinline__ void ft_write_transposed(const uint32_t (*tile)[FT_PITCH], uint16_t* __restrict__ outT, long c0, int r0,
                                                     int rows, int n) {
@@ -489,7 +506,7 @@ __device__ __forceinline__ void ft_write_transposed(const uint32_t (*tile)[FT_PI
         const int idx = it * 256 + threadIdx.x, c = idx >> 3, rg = idx & 7;
         const uint4 q = make_uint4(tile[rg * 4][c], tile[rg * 4 + 1][c], tile[rg * 4 + 2][c], tile[rg * 4 + 3][c]);
         if (c0 + c < n && r0 + rg * 8 < rows)
-            *reinterpret_cast<uint4*>(outT + (c0 + c) * (long)rows + r0 + rg * 8) = q;
+            tp_st16(outT + (c0 + c) * (long)rows + r0 + rg * 8, q.x, q.y, q.z, q.w);
     }
 }
 
@@ -505,8 +522,8 @@ __device__ __forceinline__ void store_rowpair16(uint16_t* __restrict__ out, long
         const bool odd = tx & 1;
         const uint32_t r0 = __shfl_xor(odd ? a0 : b0, 1, 64), r1 = __shfl_xor(odd ? a1 : b1, 1, 64);
         if (in) {
-            if (odd) *reinterpret_cast<uint4*>(out + (row + 1) * n + col - 4) = make_uint4(r0, r1, b0, b1);
-            else *reinterpret_cast<uint4*>(out + row * n + col) = make_uint4(a0, a1, r0, r1);
+            if (odd) tp_st16(out + (row + 1) * n + col - 4, r0, r1, b0, b1);
+            else tp_st16(out + row * n + col, a0, a1, r0, r1);
         }
     } else if (in) {
         *reinterpret_cast<uint2*>(out + row * n + col) = make_uint2(a0, a1);
@@ -518,10 +535,21 @@ __device__ __forceinline__ void store_rowpair16(uint16_t* __restrict__ out, long
 // GEMMs can leave pre-activations and feature gradients as bf16, clt_gemm_bf16_nt_out16)
 template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4(const void* __restrict__ base, long idx) {
     if (BF) {           // 16-bit activations in the active operand format
+#if TILE_NT & 1
+        const tp_u2 h = __builtin_nontemporal_load(reinterpret_cast<const tp_u2*>(static_cast<const uint16_t*>(base) + idx));
+        return make_float4(cvt16<F16>((uint16_t)(h[0] & 0xffffu)), cvt16<F16>((uint16_t)(h[0] >> 16)), cvt16<F16>((uint16_t)(h[1] & 0xffffu)),
+                           cvt16<F16>((uint16_t)(h[1] >> 16)));
+#else
         const ushort4 h = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(base) + idx);
         return make_float4(cvt16<F16>(h.x), cvt16<F16>(h.y), cvt16<F16>(h.z), cvt16<F16>(h.w));
+#endif
     }
+#if TILE_NT & 1
+    const tp_f4 t = __builtin_nontemporal_load(reinterpret_cast<const tp_f4*>(static_cast<const float*>(base) + idx));
+    return make_float4(t[0], t[1], t[2], t[3]);
+#else
     return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+#endif
 }
 
 // Guarded loads of the tile passes, branch-free: an out-of-range element reads the tensor's first element instead and is
