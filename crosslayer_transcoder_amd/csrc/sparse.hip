@@ -140,7 +140,8 @@ struct RowPassArgs {
 // keeps the per-lane state at NT = 4 (high occupancy) and combines the per-entry dots through LDS in wave order.
 // RP_HU: list entries of a column whose source rows are requested together (measured on the headline, 30 steps x 3 runs:
 // 1 / 2 / 3 / 4 / 6 -> 15.60 / 15.74 / 15.31 / 15.40 / 15.73 ms per step, the pass itself 850 -> 828 us = 0.79 of the HBM peak;
-// JumpReLU lists at 0.7 % active, PLT: 32.0 -> 28.0 ms)
+// JumpReLU lists at 0.7 % active, PLT: 32.0 -> 28.0 ms).  With the non-temporal weight streams (RP_NT): 2 / 3 / 4 -> 14.92 / 15.00 /
+// 15.20 ms — 3 is kept for the longer lists of the thresholding sparsifiers
 #ifndef RP_HU
 #define RP_HU 3
 #endif
