@@ -102,14 +102,7 @@ ROW_PASS_STREAMS = int(os.environ.get("CLT_ROWPASS_STREAMS", "2"))
 ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below which a pass is "short"
 #: short passes of one layer group in one launch (CLT_GROUP_ROW_PASSES=0: off, for A/B runs)
 GROUP_ROW_PASSES = os.environ.get("CLT_GROUP_ROW_PASSES", "1") != "0"
-_side_streams = {}
-
-
-def _side_stream(dev):
-    key = torch.device(dev).index or 0
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
-    return _side_streams[key]
+_side_stream = ops._side_stream          # (one side stream per device, shared with ops.clt_decoder_dgrad_kseg)
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
