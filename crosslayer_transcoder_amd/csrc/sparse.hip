@@ -145,6 +145,11 @@ struct RowPassArgs {
 #ifndef RP_HU
 #define RP_HU 3
 #endif
+// RP_TAIL2: a remainder of two entries after the batches of RP_HU is requested together as well (the TopK lists' columns hold
+// ~2 entries: headline launch 806 -> 791 us, 15.04 -> 14.83 ms, scripts/gpu_tail2_ab.sh)
+#ifndef RP_TAIL2
+#define RP_TAIL2 1
+#endif
 // one list entry's contribution to a lane's four gradient elements and to its share of the entry's dot — one fixed sequence
 // of fused multiply-adds wherever an entry is accumulated, so that the result does not depend on the code path that loaded it
 __device__ __forceinline__ void rp_acc4(float* __restrict__ g4, float& dot, float cv, const float4 s, const float* __restrict__ w4) {
@@ -239,11 +244,12 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
         // Columns with several entries (the JumpReLU lists' tens of tokens per feature): RP_HU entries' source rows are
         // requested together and then accumulated in list order — the same sums, a fraction of the serialised round trips.
         if constexpr (VEC && CW == 1) if (a.src_bf16) {
-            for (; p + RP_HU <= p1; p += RP_HU) {
-                float cvs[RP_HU];
-                ushort4 hh[RP_HU][NT];
+            auto batch = [&](auto nu) {                     // the next NU entries: all source-row loads first, then the sums in list order
+                constexpr int NU = decltype(nu)::value;
+                float cvs[NU];
+                ushort4 hh[NU][NT];
 #pragma unroll
-                for (int u = 0; u < RP_HU; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     cvs[u] = cf[p + u];
                     const uint16_t* rowh = srch + (long)tk[p + u] * srs;
 #pragma unroll
@@ -253,7 +259,7 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < RP_HU; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     const float cv = cvs[u];
                     float dot = 0.0f;
 #pragma unroll
@@ -270,7 +276,12 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
                         if (lane == 0) dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p + u] = dot;
                     }
                 }
-            }
+                p += NU;
+            };
+            while (p + RP_HU <= p1) batch(std::integral_constant<int, RP_HU>{});
+#if RP_HU > 2 && RP_TAIL2
+            if (p + 2 <= p1) batch(std::integral_constant<int, 2>{});      // (a remainder of two: together as well)
+#endif
         }
 #endif
         for (; p < p1; ++p) {
