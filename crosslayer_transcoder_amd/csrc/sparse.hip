@@ -398,6 +398,8 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
 }
 
 template <int NT, bool VEC, int CW, bool F16 = false, bool SQ = false>
+// (about 100 registers: 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 60 / 132 bytes per lane and the headline
+// launch goes from 787 to 971 / 1607 us, scripts/gpu_rpwaves_ab.sh)
 __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
     row_pass_body<NT, VEC, CW, F16, SQ>(a, CW == 1 ? blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
 }
