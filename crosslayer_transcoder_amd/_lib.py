@@ -57,9 +57,9 @@ SIGNATURES = {
     "clt_row_sqnorm_f32": (I, [P, I, I, P, I, P]),
     "clt_jumprelu_loss_workspace_bytes": (SZ, [I, I]),
     "clt_jumprelu_loss_bwd_f32": (I, [P, P, P, P, F32, F32, F32, I, F32, P, P, P, P, I, I, P, SZ, P]),
-    "clt_jumprelu_fwd_bf16": (I, [P, I, P, I, I, P, P, P, P]),
+    "clt_jumprelu_fwd_bf16": (I, [P, I, P, P, I, I, P, P, P, P]),
     "clt_jumprelu_loss_bf16_workspace_bytes": (SZ, [I, I]),
-    "clt_jumprelu_loss_bwd_bf16": (I, [P, I, P, P, P, I, F32, F32, F32, I, F32, P, P, P, P, P, I, I, P, SZ, P]),
+    "clt_jumprelu_loss_bwd_bf16": (I, [P, I, P, P, P, P, I, F32, F32, F32, I, F32, P, P, P, P, P, I, I, P, SZ, P]),
     "clt_rowscale_add_f32": (I, [P, P, P, P, I, I, P]),
     "clt_recon_metrics_f32": (I, [P, P, L, P, P, I, I, P, P]),
     "clt_count_positive_f32": (I, [P, I, I, P, P]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "clt_sparse_build_workspace_bytes": (SZ, [I, I, I]),
     "clt_sparse_build_f32": (I, [P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_sparse_build_threshold_f32": (I, [P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
-    "clt_sparse_build_threshold_x16": (I, [P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "clt_sparse_build_threshold_x16": (I, [P, P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_select_lists_workspace_bytes": (SZ, [I, I, I, I, I]),
     "clt_select_lists_f32": (I, [P, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_select_lists_sharded_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     "clt_gemm_bf16_nt_out16": (I, [P, P, P, I, I, I, L, L, L, I, L, L, L, P, L, P]),
     "clt_gemm_bf16_nt_kseg_out16": (I, [P, P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
-    "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, P]),
+    "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,
                                      P, P, SZ, P]),
     "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, I, I, P]),
@@ -100,7 +100,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class CltError(RuntimeError):

@@ -53,12 +53,30 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
     if ((((u & 0x7c00u) == 0x7c00u) || ((u & 0x7c000000u) == 0x7c000000u)) && clt_dev_state.inf_flag) *clt_dev_state.inf_flag = 1;
     return u;
 }
+// the same without the flag store: the caller ORs `bad` over many conversions and raises the flag once (GEMM epilogues)
+__device__ __forceinline__ uint32_t pack_f16x2_track(float lo, float hi, uint32_t& bad) {
+    typedef _Float16 clt_f16x2 __attribute__((ext_vector_type(2)));
+    typedef float clt_f32x2 __attribute__((ext_vector_type(2)));
+    const clt_f32x2 v = {lo, hi};
+    const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, clt_f16x2));
+    bad |= (uint32_t)((u & 0x7c00u) == 0x7c00u) | (uint32_t)((u & 0x7c000000u) == 0x7c000000u);
+    return u;
+}
+__device__ __forceinline__ void clt_raise_inf_flag(uint32_t bad) { if (bad && clt_dev_state.inf_flag) *clt_dev_state.inf_flag = 1; }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 // 16-bit operand conversions with the format as a template parameter (kernels are instantiated per format and picked at
 // launch from clt_host_state.fp16: the hot loops must not pay a per-element select)
 template <bool F16> __device__ __forceinline__ float cvt16(uint16_t h) { return F16 ? f16_to_f32(h) : bf16_to_f32(h); }
 template <bool F16> __device__ __forceinline__ uint32_t pack16(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 template <bool F16> __device__ __forceinline__ uint16_t to16(float f) { return (uint16_t)pack16<F16>(f, 0.0f); }
+// Round-trip through the 16-bit operand format (what a contraction RETURNS under torch.autocast: clt.py:157-165 hands the
+// encoder's einsum result on as a 16-bit tensor and adds the fp32 bias afterwards)
+template <bool F16> __device__ __forceinline__ void round16x2(float& a, float& b) {
+    const uint32_t u = pack16<F16>(a, b);
+    if (F16) { a = f16_to_f32((uint16_t)(u & 0xffffu)); b = f16_to_f32((uint16_t)(u >> 16)); }
+    else { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); }
+}
+template <bool F16> __device__ __forceinline__ float round16(float a) { float z = 0.0f; round16x2<F16>(a, z); return a; }
 // Adam kernels: true when the step is to be skipped (an overflow was seen while this step's gradients were formed)
 __device__ __forceinline__ bool clt_skip_update() { return clt_dev_state.inf_flag && *clt_dev_state.inf_flag != 0; }
 
@@ -106,7 +124,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
-                              const int32_t* gate, const float* theta = nullptr, bool theta_gate = false, bool x16 = false);
+                              const int32_t* gate, const float* theta = nullptr, bool theta_gate = false, bool x16 = false,
+                              const float* bias = nullptr);
 int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
                                 float e, void* ws, size_t wsb, hipStream_t st, const int32_t* gate);
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
@@ -119,3 +138,5 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                               hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false);
 int clt_internal_set_state_elementwise(const CltState* s);
 int clt_internal_set_state_sparse(const CltState* s);
+int clt_internal_set_state_gemm_nt(const CltState* s);
+int clt_internal_set_state_gemm(const CltState* s);

@@ -560,9 +560,18 @@ template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4z(const 
     return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
 }
 
+// ... with the per-column bias b added to the in-range elements: the 16-bit pre-activation tensor of the 16-bit modes holds the
+// encoder product alone, rounded to the operand format, and the fp32 bias joins it here in fp32 — the reference's autocast
+// order (clt.py:157-165: `pre_actvs + self.b.to(acts_norm.dtype)` after the 16-bit einsum)
+template <bool BF, bool F16> __device__ __forceinline__ float4 act_load4zb(const void* __restrict__ base, long idx, bool ok, const float4 b) {
+    const float4 v = act_load4<BF, F16>(base, ok ? idx : 0);
+    return make_float4(ok ? v.x + b.x : 0.0f, ok ? v.y + b.y : 0.0f, ok ? v.z + b.z : 0.0f, ok ? v.w + b.w : 0.0f);
+}
+
 // grid (ceil(n/256), ceil(rows/64)); rows % 8 == 0, n % 4 == 0
 template <bool XB, bool F16>
-__global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta, int rows,
+__global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
+                                                                const float* __restrict__ bias, int rows,
                                                                 int n, uint16_t* __restrict__ feat, uint16_t* __restrict__ featT,
                                                                 uint8_t* __restrict__ fired) {
     __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
@@ -573,6 +582,8 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
     const bool cin = col < n;
     float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (theta && cin) th = *reinterpret_cast<const float4*>(theta + col);
+    float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (bias && cin) bb = *reinterpret_cast<const float4*>(bias + col);
     bool any[4] = {false, false, false, false};
 // (variants measured at B*L*F = 1.61 G, bf16 in, scripts/jf_probe.py: 2 / 4 / 8 row pairs ahead 1966 / 1996 / 1987 us, 16-byte
 // row stores by lane exchange 1997 us: the pass writes twice what it reads and sits at ~4.9 TB/s either way)
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 #pragma unroll
         for (int u = 0; u < 2 * JF_AHEAD; ++u) {
             const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
-            vv[u] = act_load4z<XB, F16>(x, (long)row * n + col, cin && row < rows);
+            vv[u] = act_load4zb<XB, F16>(x, (long)row * n + col, cin && row < rows, bb);
         }
 #pragma unroll
         for (int u = 0; u < JF_AHEAD; ++u) {
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WP_WAVES)))
 // registers.  part: [3][gridDim.y][n] floats (dtheta, dnorm, dbias partials) then [nblocks][3] doubles.
 template <bool XB, bool GB, bool TANH, bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JL_WAVES))) void jumprelu_loss_bf16_kernel(const void* __restrict__ x, const float* __restrict__ theta,
-                                                                 const float* __restrict__ sq, const void* __restrict__ dfm, float bw,
+                                                                 const float* __restrict__ bias, const float* __restrict__ sq, const void* __restrict__ dfm, float bw,
                                                                  float lamB, float c, float coefBL,
                                                                  uint16_t* __restrict__ dpreT, float* __restrict__ part,
                                                                  double* __restrict__ part_s, int rows, int n) {
@@ -718,6 +729,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JL_WAVES)))
         th[0] = t4.x; th[1] = t4.y; th[2] = t4.z; th[3] = t4.w;
         nrm[0] = sqrtf(s4.x); nrm[1] = sqrtf(s4.y); nrm[2] = sqrtf(s4.z); nrm[3] = sqrtf(s4.w);
     }
+    float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (bias && cin) bb = *reinterpret_cast<const float4*>(bias + col);
     float thc[4], nc[4], nc2[4], lcn[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JL_WAVES)))
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
-                v4[u] = act_load4z<XB, F16>(x, (long)row * n + col, cin && row < rows);
+                v4[u] = act_load4zb<XB, F16>(x, (long)row * n + col, cin && row < rows, bb);
                 g4[u] = act_load4z<GB, F16>(dfm, (long)row * n + col, cin && row < rows);
             }
 #pragma unroll
@@ -969,7 +982,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 9; }
+int clt_abi_version(void) { return 10; }
 
 int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
     if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;
@@ -979,6 +992,8 @@ int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf
     const CltState s = {fp16_operands ? 1 : 0, 1.0f / loss_scale, reinterpret_cast<int*>(found_inf)};
     int rc = clt_internal_set_state_elementwise(&s);
     if (rc == CLT_OK) rc = clt_internal_set_state_sparse(&s);
+    if (rc == CLT_OK) rc = clt_internal_set_state_gemm_nt(&s);
+    if (rc == CLT_OK) rc = clt_internal_set_state_gemm(&s);
     if (rc == CLT_OK) clt_host_state = s;
     return rc;
 }
@@ -1177,13 +1192,14 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
-int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT,
-                          uint8_t* fired, void* st) {
+int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, const float* bias, int rows, int n, uint16_t* feat,
+                          uint16_t* featT, uint8_t* fired, void* st) {
     if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
-    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta))) return CLT_ERR_ALIGN;
+    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta)) ||
+        (bias && !aligned16(bias))) return CLT_ERR_ALIGN;
     if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
     const dim3 grid((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R);
-#define JF(XB_, F_) hipLaunchKernelGGL((jumprelu_fwd_bf16_kernel<XB_, F_>), grid, dim3(256), 0, as_stream(st), x, theta, rows, n, feat, featT, fired)
+#define JF(XB_, F_) hipLaunchKernelGGL((jumprelu_fwd_bf16_kernel<XB_, F_>), grid, dim3(256), 0, as_stream(st), x, theta, bias, rows, n, feat, featT, fired)
     if (clt_host_state.fp16) { if (x_bf16) JF(true, true); else JF(false, true); }
     else if (x_bf16) JF(true, false);
     else JF(false, false);
@@ -1194,16 +1210,17 @@ size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n) {
     const size_t gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C;
     return align_up(3 * gy * (size_t)n * sizeof(float), 16) + gx * gy * 3 * sizeof(double);
 }
-int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* sq, const void* dfm, int dfm_bf16, float bw,
+int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* bias, const float* sq, const void* dfm, int dfm_bf16, float bw,
                                float lamB, float c, int use_tanh, float coefBL, uint16_t* dpreT, float* dbias, float* dtheta,
                                float* dnorm, double* sums, int rows, int n, void* ws, size_t wsb, void* st) {
     if (rows <= 0 || n <= 0 || !x || !theta || !sq || !dfm || !dpreT || !dbias || !dtheta || !dnorm || !sums) return CLT_ERR_SHAPE;
-    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(theta) || !aligned16(sq) || !aligned16(dfm) || !aligned16(dpreT)) return CLT_ERR_ALIGN;
+    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(theta) || !aligned16(sq) || !aligned16(dfm) || !aligned16(dpreT) ||
+        (bias && !aligned16(bias))) return CLT_ERR_ALIGN;
     if (!ws || wsb < clt_jumprelu_loss_bf16_workspace_bytes(rows, n)) return CLT_ERR_WORKSPACE;
     const int gy = (rows + 4 * FT_R - 1) / (4 * FT_R), gx = (n + FT_C - 1) / FT_C, gc = (n + TPB - 1) / TPB;
     float* part = (float*)ws;
     double* ps = (double*)((char*)ws + align_up((size_t)3 * gy * n * sizeof(float), 16));
-#define JL2(XB_, GB_, TH_, F_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_, F_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, sq, \
+#define JL2(XB_, GB_, TH_, F_) hipLaunchKernelGGL((jumprelu_loss_bf16_kernel<XB_, GB_, TH_, F_>), dim3(gx, gy), dim3(256), 0, as_stream(st), x, theta, bias, sq, \
                                                  dfm, bw, lamB, c, coefBL, dpreT, part, ps, rows, n)
 #define JL(XB_, GB_, F_) do { if (use_tanh) JL2(XB_, GB_, true, F_); else JL2(XB_, GB_, false, F_); } while (0)
 #define JLF(F_) do { if (x_bf16) { if (dfm_bf16) JL(true, true, F_); else JL(true, false, F_); } \

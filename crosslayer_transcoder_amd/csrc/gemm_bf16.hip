@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const uint16_t* __restri
                 const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < M) {
                     float* dst = C + (long)row * ldc + col;
-                    float v = acc[mi][ni][r] + bv;
-                    if (accumulate) v += *dst;
+                    float v = ((accumulate & CLT_GEMM_ROUND_ACC) ? round16<F16>(acc[mi][ni][r]) : acc[mi][ni][r]) + bv;
+                    if (accumulate & CLT_GEMM_ACCUMULATE) v += *dst;
                     *dst = v;
                 }
             }
@@ -147,6 +147,8 @@ int launch(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, 
     return CLT_OK;
 }
 }  // namespace
+
+CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_gemm)
 
 extern "C" int clt_gemm_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb,
                              long ldc, int transA, int transB, int batch, long sA, long sB, long sC,

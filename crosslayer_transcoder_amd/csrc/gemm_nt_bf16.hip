@@ -32,6 +32,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GEMM_NT_STORE 1
 #endif
 namespace {
+// 16-bit conversions of the epilogues: an fp16 overflow is collected in `bad` and raises the loss scaler's flag once per tile
+template <bool F16> __device__ __forceinline__ uint32_t pack16t(float lo, float hi, uint32_t& bad) {
+    if constexpr (F16) return pack_f16x2_track(lo, hi, bad); else return pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ f32x4 round16v(f32x4 v, uint32_t& bad) {
+    const uint32_t u0 = pack16t<F16>(v[0], v[1], bad), u1 = pack16t<F16>(v[2], v[3], bad);
+    if constexpr (F16) return f32x4{f16_to_f32((uint16_t)(u0 & 0xffffu)), f16_to_f32((uint16_t)(u0 >> 16)), f16_to_f32((uint16_t)(u1 & 0xffffu)), f16_to_f32((uint16_t)(u1 >> 16))};
+    else return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u)};
+}
 constexpr int TB = 256, TA = 256, TK = 64;              // tile: B rows (C columns), A rows (C rows), k
 constexpr int OP_BYTES = 256 * TK * 2;                  // one operand tile in LDS (32 KiB)
 constexpr int STAGE_BYTES = 2 * OP_BYTES;               // B tile | A tile
@@ -68,7 +77,7 @@ template <int EPI, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
-                                                           long sBias, int accumulate, int tilesA, int tilesB, int total, int diag_arg,
+                                                           long sBias, int gflags, int tilesA, int tilesB, int total, int diag_arg,
                                                            SelEpi se, const uint16_t* const* __restrict__ Bseg, int kts,
                                                            const GemmGroup* __restrict__ grp) {
 #ifdef CLT_DIAG
@@ -76,6 +85,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
 #else
     constexpr int diag = 0;
 #endif
+    // gflags: CLT_GEMM_ACCUMULATE (C +=), CLT_GEMM_ROUND_ACC (the product is rounded to the operand format before the bias is
+    // added: the encoder forward of the 16-bit modes, whose einsum result is a 16-bit tensor under the reference's autocast)
+    const int accumulate = EPI == 0 ? (gflags & CLT_GEMM_ACCUMULATE) : 0;
+    const bool racc = EPI != 2 && (gflags & CLT_GEMM_ROUND_ACC) != 0;      // (16-bit C: rounded by the store itself)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         const int batch = cur.batch, a0 = cur.a0, b0 = cur.b0;
         const float* bias = bias0 ? reinterpret_cast<const float*>(nt_smem + BIAS_BASE + slot * 1024) : nullptr;   // [256] in LDS
         slot ^= 1;
+        uint32_t bad16 = 0;                              // fp16 mode: some conversion of this tile's epilogue overflowed
 
         if (EPI == 1) {
             // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
@@ -290,7 +304,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int row = a0 + wn * 64 + n * 16 + fr;
-                    const f32x4 v = acc[m][n] + bv;
+                    f32x4 v = acc[m][n];
+                    if (racc) v = round16v<F16>(v, bad16);
+                    v += bv;
                     const bool in = row < M && col < N;
                     const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
                     if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
@@ -348,8 +364,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         typedef __attribute__((address_space(1))) u32x4 gvec;
                         u32x4 o;
-                        o[0] = pack16<F16>(v0[0], v0[1]); o[1] = pack16<F16>(v0[2], v0[3]);
-                        o[2] = pack16<F16>(v1[0], v1[1]); o[3] = pack16<F16>(v1[2], v1[3]);
+                        o[0] = pack16t<F16>(v0[0], v0[1], bad16); o[1] = pack16t<F16>(v0[2], v0[3], bad16);
+                        o[2] = pack16t<F16>(v1[0], v1[1], bad16); o[3] = pack16t<F16>(v1[2], v1[3], bad16);
 #if GEMM_NT_STORE
                         __builtin_nontemporal_store(o, (gvec*)(C + (long)row * ldc + col));
 #else
@@ -386,6 +402,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         // would be flat_store — slower, and outside the in-order vmcnt accounting used at the loop top)
                         typedef __attribute__((address_space(1))) f32x4 gvec;
                         gvec* dst = (gvec*)(C + (long)row * ldc + col);
+                        if (racc) v = round16v<F16>(v, bad16);
                         v += bv;
                         if (accumulate) { const f32x4 old = *dst; v += old; }
 #if GEMM_NT_STORE
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (F16) clt_raise_inf_flag(bad16);
         if (!more) break;
         stores_after_prefetch = EPI != 1 && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
         vb = nvb;
@@ -431,6 +449,9 @@ int persistent_grid(long nblk) {
 }
 }  // namespace
 
+// (the fp16 store / rounding epilogues raise the loss scaler's overflow flag: this unit needs the state too)
+CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_gemm_nt)
+
 // Returns CLT_OK when the fast kernel was launched, 1 when the shape/alignment does not qualify (caller falls back
 // to the generic kernel), or a negative error.
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
@@ -438,7 +459,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
                               hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
     // bf16 result (C is then a bf16 array; ldc / sC in bf16 elements): 8-column alignment, no accumulate, no groups
-    if (out16 && (accumulate || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
+    if (out16 && ((accumulate & CLT_GEMM_ACCUMULATE) || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
     const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
                     (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
@@ -522,7 +543,7 @@ extern "C" int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, i
 // index of an element.  Returns 1 when the shape does not qualify for the fast kernel.
 extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, long ldc, int batch,
                                     long sA, long sB, long sC, const float* bias, long sBias, const uint32_t* ctl,
-                                    uint32_t* cand_key, uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream) {
+                                    uint32_t* cand_key, uint32_t* cand_idx, uint32_t capS, int seg_per_batch, int flags, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !ctl || !cand_key || !cand_idx || capS == 0) return CLT_ERR_SHAPE;
     const bool ok = K % 8 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
                     aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) && dma_offsets_fit(lda, ldb, K);
@@ -535,7 +556,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
-                           (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(),
+                           (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, flags & CLT_GEMM_ROUND_ACC, tilesA, tilesB, (int)nblk, gemm_diag(),
                            SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0, (const GemmGroup*)nullptr);
         CLT_LAUNCH_CHECK();
         return CLT_OK;
@@ -543,7 +564,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
-                       (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk,
+                       (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, flags & CLT_GEMM_ROUND_ACC, tilesA, tilesB, (int)nblk,
                        gemm_diag(),
                        SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0,
                        (const GemmGroup*)nullptr);

@@ -71,9 +71,12 @@ __device__ __forceinline__ uint32_t rows_hits(const float4 x, const float4 t) {
     return (uint32_t)(x.x > 0.0f && x.x > t.x) + (uint32_t)(x.y > 0.0f && x.y > t.y) + (uint32_t)(x.z > 0.0f && x.z > t.z) +
            (uint32_t)(x.w > 0.0f && x.w > t.w);
 }
+// bias ([L*F], optional): added to every element in fp32 before the comparison and in the stored value — the 16-bit
+// pre-activation tensor of the 16-bit modes holds the rounded encoder product alone (autocast order, clt.py:157-165).
+__device__ __forceinline__ float4 rows_add4(const float4 x, const float4 b) { return make_float4(x.x + b.x, x.y + b.y, x.z + b.z, x.w + b.w); }
 template <int XT, bool TH>
 __global__ __launch_bounds__(LTPB) void count_rows_th_kernel(const void* __restrict__ feat, int B, int F, int L, const float* __restrict__ theta,
-                                                            uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on,
+                                                            const float* __restrict__ bias, uint32_t* __restrict__ row_cnt, const int32_t* __restrict__ gate, int gate_on,
                                                             uint32_t* __restrict__ wave_cnt) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
     constexpr int R = ROWS_PER_BLOCK, XB = XT == 0 ? 4 : 2;
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(LTPB) void count_rows_th_kernel(const void* __restr
     const int l = blockIdx.x % L, b0 = (blockIdx.x / L) * R;
     const int nb = min(R, B - b0);                         // >= 1 by the grid
     const float* th = TH ? theta + (long)l * F : nullptr;
+    const float* bi = bias ? bias + (long)l * F : nullptr;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg = rows_seg(F, true);
     const int s0 = min(F, w * seg), s1 = min(F, s0 + seg);
@@ -96,6 +100,11 @@ __global__ __launch_bounds__(LTPB) void count_rows_th_kernel(const void* __restr
         float4 x[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = rows_ld4<XT>(xr[j], i);
+        if (bi) {
+            const float4 bv = *reinterpret_cast<const float4*>(bi + i);
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j] = rows_add4(x[j], bv);
+        }
 #pragma unroll
         for (int j = 0; j < R; ++j) c[j] += rows_hits(x[j], t);
     }
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(LTPB) void count_rows_th_kernel(const void* __restr
 
 template <int XT, bool TH>
 __global__ __launch_bounds__(LTPB) void fill_rows_th_kernel(const void* __restrict__ feat, int B, int F, int L, const float* __restrict__ theta,
-                                                           const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
+                                                           const float* __restrict__ bias, const uint32_t* __restrict__ row_start, int32_t* __restrict__ ent_col,
                                                            float* __restrict__ ent_val, uint32_t cap, int32_t* __restrict__ overflow,
                                                            const int32_t* __restrict__ gate, int gate_on, const uint32_t* __restrict__ wave_cnt) {
     if (gate && (*gate != 0) != (gate_on != 0)) return;
@@ -119,6 +128,7 @@ __global__ __launch_bounds__(LTPB) void fill_rows_th_kernel(const void* __restri
     const int l = blockIdx.x % L, b0 = (blockIdx.x / L) * R;
     const int nb = min(R, B - b0);
     const float* th = TH ? theta + (long)l * F : nullptr;
+    const float* bi = bias ? bias + (long)l * F : nullptr;
     const int colbase = l * F;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg = rows_seg(F, true);
@@ -142,6 +152,11 @@ __global__ __launch_bounds__(LTPB) void fill_rows_th_kernel(const void* __restri
         float4 x[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = rows_ld4<XT>(xr[j], ii);
+        if (bi) {
+            const float4 bv = *reinterpret_cast<const float4*>(bi + ii);
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j] = rows_add4(x[j], bv);
+        }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (j >= nb) continue;                         // (block-uniform)

@@ -237,10 +237,11 @@ __global__ __launch_bounds__(TPB) void ties_kernel(const uint32_t* __restrict__ 
 }
 // own tie block: overflow -> gate; more entries than the lists hold -> gate bit 2; publish the local gate in the block so
 // that the gather carries it
+// (tie_lists = 0: the ties are ranked by the index radix select, a tie block that overflowed is no reason to give up)
 __global__ void check_ties_kernel(int S, Shard sd, uint32_t* __restrict__ tie_region, Head* __restrict__ head,
-                                  const SegState* __restrict__ state, uint32_t capsel) {
+                                  const SegState* __restrict__ state, uint32_t capsel, int tie_lists) {
     uint32_t* blk = tie_region + sd.rank * tie_block_words(S);
-    for (int s = threadIdx.x; s < S; s += blockDim.x) if (blk[s] > TIECAP) atomicOr(&head->gate, 1);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) if (tie_lists && blk[s] > TIECAP) atomicOr(&head->gate, 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long bound = head->above_cnt;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(TPB) void tie_hist_kernel(const uint32_t* __restric
     const int shift = 24 - 8 * round;
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t n = ctl[s].cand_cnt;
+    const uint32_t n = min(ctl[s].cand_cnt, capS);         // (an overflowed candidate buffer has raised the gate: nothing is emitted)
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
         if (cand_key[(size_t)s * capS + i] != st.prefix) continue;
         const uint32_t gi = global_index(cand_idx[(size_t)s * capS + i], F, sd);
@@ -393,7 +394,7 @@ struct LPlan {
     int S, RS, rows, ncols, rpb, NC;
     uint32_t Kseg, ns, rank, capS;
     size_t tie_words;
-    size_t off_ctl, off_state, off_ghist, off_tie, off_rowcnt, off_rowcur, off_colcnt, off_colcur, zero_end;
+    size_t off_ctl, off_state, off_ghist, off_tie, off_tiex, off_rowcnt, off_rowcur, off_colcnt, off_colcur, zero_end;
     size_t off_long, off_sample, off_ckey, off_cidx, off_sidx, off_sval, off_fbsel, off_fbbuild, total;
 };
 
@@ -424,6 +425,7 @@ LPlan lplan(int B, int L, int F, int k, int mode, int world, int flags) {
     p.off_state = take((size_t)p.S * sizeof(SegState));
     p.off_ghist = take((size_t)p.S * NBIN * 4 + (size_t)p.S * 4);          // histograms | per-segment candidate totals
     p.off_tie = take(mode == 0 ? 0 : p.tie_words * 4 * world);
+    p.off_tiex = take(mode == 0 ? 0 : (size_t)p.S * 16);                    // TieX[S]: state of the index radix select
     p.off_rowcnt = take((size_t)p.rows * 4);
     p.off_rowcur = take((size_t)p.rows * 4);
     p.off_colcnt = take((size_t)p.ncols * 4);
@@ -510,8 +512,13 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     const dim3 cgrid(nbk, p.S);
     const bool split = (a.exhaustive & 4) != 0;
     const bool tie_radix = (a.exhaustive & 8) != 0;        // exact for any number of ties: index radix select, no tie lists
+    // One GPU: ties at the k-th value are ALWAYS resolved by the index radix select (four histogram + find rounds over the
+    // candidates inside stage 4, no exchange).  In the 16-bit modes the pre-activations are 16-bit products + fp32 bias (the
+    // reference's autocast values): with the initial zero bias tens of thousands of entries tie at the k-th value of the
+    // headline shape (63 034 measured), far beyond a tie block, and the exhaustive dense fallback would run instead.
+    const bool local_radix = !tie_radix && a.sd.world == 1 && mode != 0;
     const int last_stage = tie_radix ? 8 : (split ? 6 : 5);
-    TieX* tiex = (TieX*)tie_region;                        // (the tie blocks are unused in that form; zeroed in stage 0)
+    TieX* tiex = (TieX*)(w8 + p.off_tiex);                 // (zeroed in stage 0)
 
     for (int stage = lo; stage <= hi; ++stage) {
         if (stage == 0) {
@@ -567,12 +574,23 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
             hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
                                long_list, &head->long_rows, gate, 0);
+        } else if (stage == 4 && local_radix) {
+            hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
+            // (the tie pass still counts what this shard will emit, for the list-capacity gate; its tie lists are not used)
+            hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
+            const unsigned long long kall4 = (unsigned long long)p.Kseg * p.S;
+            hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head, state,
+                               a.cap < kall4 ? a.cap : (uint32_t)kall4, 0);
+            for (int r = 0; r < 4; ++r) {
+                hipLaunchKernelGGL(tie_hist_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tiex, F, a.sd, ghist, r);
+                hipLaunchKernelGGL(tie_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, tiex, ghist, r);
+            }
         } else if (stage == 4) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             hipLaunchKernelGGL(ties_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, p.S, F, a.sd, tie_region, head);
             const unsigned long long kall4 = (unsigned long long)p.Kseg * p.S;
             hipLaunchKernelGGL(check_ties_kernel, dim3(1), dim3(64), 0, st, p.S, a.sd, tie_region, head, state,
-                               a.cap < kall4 ? a.cap : (uint32_t)kall4);
+                               a.cap < kall4 ? a.cap : (uint32_t)kall4, 1);
         } else if (stage == 5 || stage == 6) {
             // split (flags & 4, the ext entry point): stage 5 = merge the gate and publish it, stage 6 = emit + lists —
             // the host can read the outcome flag while stage 6 still runs
@@ -586,7 +604,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             const unsigned long long kall = (unsigned long long)p.Kseg * p.S;
             const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
             hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
-                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, (const TieX*)nullptr);
+                               sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, local_radix ? tiex : (const TieX*)nullptr);
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);

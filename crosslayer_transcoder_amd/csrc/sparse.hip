@@ -486,7 +486,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_sparse)
 int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
-                              const int32_t* gate, const float* theta, bool theta_gate, bool x16) {
+                              const int32_t* gate, const float* theta, bool theta_gate, bool x16, const float* bias) {
     const int xt = x16 ? (clt_host_state.fp16 ? 2 : 1) : 0;     // element type of feat: fp32 / bf16 / fp16
     if (B <= 0 || L <= 0 || F <= 0 || cap == 0) return CLT_ERR_SHAPE;
     if ((unsigned long long)L * F >= 0x7fffffffull || (unsigned long long)B * L >= 0x7fffffffull) return CLT_ERR_RANGE;
@@ -507,12 +507,13 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
     // thresholds + vector form (every row has it when the bases are aligned and F % 4 == 0): four rows of a layer per block
     const bool th4 = F % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & (uintptr_t)(xt == 0 ? 15 : 7)) == 0 &&
                      (!theta || (reinterpret_cast<uintptr_t>(theta) & 15) == 0);
+    if (bias && (!th4 || (reinterpret_cast<uintptr_t>(bias) & 15))) return CLT_ERR_ALIGN;      // (a bias only in the vector form)
     const dim3 g4((unsigned)(((B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * L));
     if (th4) {
 #define COUNT_ROWS_TH(XT_)                                                                                                 \
     do {                                                                                                                    \
-        if (theta) hipLaunchKernelGGL((count_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_cnt, gate, 1, wave_cnt); \
-        else hipLaunchKernelGGL((count_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_cnt, gate, 1, wave_cnt);    \
+        if (theta) hipLaunchKernelGGL((count_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, bias, row_cnt, gate, 1, wave_cnt); \
+        else hipLaunchKernelGGL((count_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, bias, row_cnt, gate, 1, wave_cnt);    \
     } while (0)
         if (xt == 0) COUNT_ROWS_TH(0); else if (xt == 1) COUNT_ROWS_TH(1); else COUNT_ROWS_TH(2);
 #undef COUNT_ROWS_TH
@@ -530,9 +531,9 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
                                           overflow, gate, 1, (const uint32_t*)wave_cnt)
 #define FILL_ROWS_TH(XT_)                                                                                                  \
     do {                                                                                                                    \
-        if (theta) hipLaunchKernelGGL((fill_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_start, ent_col, ent_val, \
+        if (theta) hipLaunchKernelGGL((fill_rows_th_kernel<XT_, true>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, bias, row_start, ent_col, ent_val, \
                                       cap, overflow, gate, 1, (const uint32_t*)wave_cnt);                                    \
-        else hipLaunchKernelGGL((fill_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, row_start, ent_col, ent_val,     \
+        else hipLaunchKernelGGL((fill_rows_th_kernel<XT_, false>), g4, dim3(TPB), 0, st, feat, B, F, L, theta, bias, row_start, ent_col, ent_val,     \
                                 cap, overflow, gate, 1, (const uint32_t*)wave_cnt);                                          \
     } while (0)
     if (th4) { if (xt == 0) FILL_ROWS_TH(0); else if (xt == 1) FILL_ROWS_TH(1); else FILL_ROWS_TH(2); }
@@ -572,13 +573,13 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
                                      total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true);
 }
 
-int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, const float* bias, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb,
                                    void* stp) {
     if (F % 4 || (reinterpret_cast<uintptr_t>(x) & 7)) return CLT_ERR_ALIGN;
     return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
-                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, true);
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, true, bias);
 }
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,

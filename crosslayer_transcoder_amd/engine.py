@@ -441,17 +441,17 @@ class _Decoder:
         return dval, dval2
 
 
-def _threshold_lists(mod, pre, theta, force: bool):
+def _threshold_lists(mod, pre, theta, force: bool, bias=None):
     """Activation lists of a thresholding sparsifier (JumpReLU: theta; ReLU: None) from its pre-activations, or None
     when more than LIST_MAX_DENSITY of the entries are active (the dense regime is then cheaper).  force: no gate."""
     Bn, L, F = pre.shape
     full = Bn * L * F
     if force:
-        return ops.sparse_build_threshold(pre, theta, full)
+        return ops.sparse_build_threshold(pre, theta, full, bias)
     if getattr(mod, "_list_skip", 0) > 0:            # recently above the break-even: no attempt this step
         mod._list_skip -= 1
         return None
-    S = ops.sparse_build_threshold(pre, theta, max(1, int(LIST_MAX_DENSITY * full)))
+    S = ops.sparse_build_threshold(pre, theta, max(1, int(LIST_MAX_DENSITY * full)), bias)
     if ops.read_flag(S.overflow) != 0:
         mod._list_retry = min(LIST_RETRY_MAX, 2 * getattr(mod, "_list_retry", LIST_RETRY_FIRST // 2))
         mod._list_skip = mod._list_retry
@@ -485,6 +485,14 @@ def _exchange_groups(L):
         out.append((lo, hi))
         hi = lo
     return out
+
+
+def agree_on_overflow(shard, flag):
+    """fp16 mode under feature sharding: the conversions of a step are per shard, so an overflow may raise the flag on one
+    rank only; the Adam kernels and the loss scaler of EVERY rank must see it (replicated parameters and the scale would
+    diverge for good otherwise).  SUM over ranks of the device flag, in place; non-zero = skip."""
+    if shard is not None and flag is not None and (shard.world > 1 or shard.keep_single):
+        flag.copy_(shard.all_reduce_sum(flag.clone()))
 
 
 def _list_capacity(nl, Bn, L, F):
@@ -627,14 +635,20 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     # attempt is made this step, clt_sparse_build_threshold_x16) read half the bytes
     attempt = bool(sparse and thr_family and (force_lists or getattr(mod, "_list_skip", 0) == 0))
     act16 = bool(DENSE_BF16_ACTIVATIONS and fuse_jump and S is None and (not attempt or (LIST_BF16_ACTIVATIONS and F % 4 == 0)))
+    # 16-bit pre-activation tensor: with ops.AUTOCAST_PRE it holds the encoder PRODUCT alone (the reference's einsum result
+    # under autocast is this 16-bit tensor) and every consumer adds the fp32 bias in fp32 (`pre_bias`), autocast's order
+    pre_bias = None
     if S is None:
-        pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), enc.b) if act16 else None
+        split_bias = bool(act16 and ops.AUTOCAST_PRE and enc.b is not None)
+        pre = ops.encoder_fwd_out16(xo, _encoder_operand(enc), None if split_bias else enc.b) if act16 else None
         if pre is None:
             act16 = False
             pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
+        elif split_bias:
+            pre_bias = enc.b
     if S is None and sparse and thr_family:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
-        S = _threshold_lists(mod, pre, theta, force_lists)
+        S = _threshold_lists(mod, pre, theta, force_lists, pre_bias)
         if S is None:
             sparse = False                       # above the break-even density: dense GEMM regime for this step
     if S is not None:
@@ -647,7 +661,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 nl._kth_probe = ops.FlagProbe(S.used_fallback)        # (read at the next step, without blocking)
     elif fuse_jump:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
-        fused_ops = ops.jumprelu_fwd_bf16(pre, theta)            # (feat bf16, feat^T bf16, fired)
+        fused_ops = ops.jumprelu_fwd_bf16(pre, theta, pre_bias)  # (feat bf16, feat^T bf16, fired)
     elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)
@@ -760,13 +774,13 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     if pre is not None and not act16:
         out["pre_actvs"] = pre
     elif pre is not None:
-        out.lazy["pre_actvs"] = lambda: pre.float()
+        out.lazy["pre_actvs"] = lambda: pre.float() if pre_bias is None else pre.float() + pre_bias
     else:
         out.lazy["pre_actvs"] = lambda: ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
     if feat is not None:
         out["features"] = feat
     elif fused_ops is not None:
-        pre32 = (lambda: pre.float()) if act16 else (lambda: pre)
+        pre32 = (lambda: out["pre_actvs"]) if act16 else (lambda: pre)
         out.lazy["features"] = (lambda: ops.jumprelu_fwd(pre32(), theta)) if theta is not None else (lambda: ops.relu_fwd(pre32()))
 
     if lists_only:
@@ -844,6 +858,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 dWt_c = ops.encoder_wgrad(xs32, dpre_c)
             extra_dec = (gc, cmap)
             extra_enc = (dWt_c.view(-1, d), cmap, db_c.view(-1))
+        if fp16:                                  # every rank takes the same skip decision in the Adam-carrying row passes
+            agree_on_overflow(shard, flag)
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
                                    slabs=slabs, groups=groups if pipelined else None)
         if pipelined:
@@ -883,14 +899,14 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
         if loss16:
             sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
-                                                                  mod.pre_actv_loss / (Bn * L))
+                                                                  mod.pre_actv_loss / (Bn * L), bias=pre_bias)
         else:
             sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
                                                         mod.pre_actv_loss / (Bn * L))
         if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
             sums = shard.all_reduce_sum(sums.clone())
             if fp16:                          # d(pre) is per shard: every rank must take the same skip decision
-                flag.copy_(shard.all_reduce_sum(flag.clone()))
+                agree_on_overflow(shard, flag)
         if S is not None:
             # list regime: dW_l[l', i, :] = sum over the tokens where feature (l', i) is active of val * g[tok, l, :], plus the
             # row's dec_norms term — one streaming pass per decoder matrix, Adam applied in it when an optimizer is handed in

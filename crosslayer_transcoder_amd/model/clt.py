@@ -79,12 +79,18 @@ class Encoder(SerializableModule):
 
     @torch.no_grad()
     def fold(self, input_standardizer: Standardizer):
-        """W <- W / std[..., None]; b <- b - mean @ W_folded (clt.py:169-185).  One-off export step,
-        not part of the training hot path, so plain tensor algebra is used."""
+        """W <- W / std[..., None]; b <- b - mean @ W_folded (clt.py:169-185).  One-off export step.  On the GPU the
+        contraction goes through the library's exact-fp32 GEMM like every other contraction of the package (no torch GPU
+        GEMM anywhere); a module held on the CPU (export tooling) uses plain tensor algebra."""
         if self._is_folded:
             return self
         self.W.data = self.W / input_standardizer.std.unsqueeze(-1)
-        self.b.data = self.b - torch.einsum("ld,ldf->lf", input_standardizer.mean, self.W)
+        if self.W.is_cuda:
+            from .. import ops
+            mw = ops.encoder_fwd(input_standardizer.mean.float().unsqueeze(0).contiguous(), self.Wt.contiguous(), None)[0]
+        else:
+            mw = torch.einsum("ld,ldf->lf", input_standardizer.mean, self.W)
+        self.b.data = self.b - mw
         self._is_folded = True
         return self
 

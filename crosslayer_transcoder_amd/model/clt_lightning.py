@@ -225,9 +225,19 @@ class CrossLayerTranscoderModule(_Base):
         scaler = getattr(self, "loss_scaler", None) if get_precision() == "fp16" else None
         if scaler is not None:
             # fp16 loss scaling is the library's own (the kernels unscale and skip): the raw optimizer steps, not a wrapper that
-            # would route through an outer GradScaler; one host read of the overflow flag closes the step
+            # would route through an outer GradScaler; one host read of the overflow flag closes the step.  Under Lightning's
+            # manual optimisation trainer.global_step advances in the LightningOptimizer's _on_before_step / _on_after_step
+            # hooks (optim_step_progress): they are called around the raw step, so max_steps, the lambda schedule
+            # (global_step / max_steps) and step-based logging move in this mode as well.
+            flag = ops.inf_flag(batch.device)
+            engine.agree_on_overflow(getattr(self, "shard", None), flag)     # (feature shards: one decision for all ranks)
+            before, after = getattr(stepper, "_on_before_step", None), getattr(stepper, "_on_after_step", None)
+            if callable(before):
+                before()
             optimizer.step()
-            skipped = bool(ops.inf_flag(batch.device).item())
+            if callable(after):
+                after()
+            skipped = bool(flag.item())
             optimizer.commit(skipped)
             scaler.update(skipped)
             self.log("training/loss_scale", scaler.scale)

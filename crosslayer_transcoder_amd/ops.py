@@ -22,7 +22,8 @@ _DT16 = (torch.bfloat16, torch.float16)
 #: gradients are formed multiplied by this factor (the loss kernels' coefficients carry it) and unscaled inside the Adam
 #: kernels; 1.0 outside fp16 mode.  Set through set_loss_scaling only.
 GRAD_SCALE = 1.0
-_lib_state = (False, 1.0, 0)
+_lib_state = {}            # per device: the library keeps this state in each device's constant memory
+_STATE0 = (False, 1.0, 0)
 _flags = {}
 
 
@@ -37,15 +38,16 @@ def inf_flag(device) -> torch.Tensor:
 def set_loss_scaling(fp16: bool, scale: float = 1.0, flag: Optional[torch.Tensor] = None):
     """Bring the library state in line with (operand format, loss scale, overflow flag); a C call (which synchronises the
     device) only when something changed."""
-    global _lib_state, GRAD_SCALE
+    global GRAD_SCALE
+    dev = torch.cuda.current_device()
     if fp16 and flag is None:
-        flag = inf_flag(torch.cuda.current_device())
-    if flag is not None and flag.device.index != torch.cuda.current_device():
+        flag = inf_flag(dev)
+    if flag is not None and flag.device.index != dev:
         raise RuntimeError("loss-scaling state applies to the current device: run the fp16 step with torch.cuda.set_device(module's device)")
     want = (bool(fp16), float(scale), flag.data_ptr() if flag is not None else 0)
-    if want != _lib_state:
+    if want != _lib_state.get(dev, _STATE0):
         call("clt_set_loss_scaling", int(want[0]), want[1], want[2] or None)
-        _lib_state = want
+        _lib_state[dev] = want
     GRAD_SCALE = want[1]
 
 
@@ -54,7 +56,10 @@ def sync_operand_format():
     from the active precision, no loss scaling of the library's own (an outer GradScaler scales and unscales)."""
     from .precision import get_precision
     fp16 = get_precision() == "fp16"
-    if fp16 != _lib_state[0] or _lib_state[1] != 1.0:
+    state = _lib_state.get(torch.cuda.current_device(), _STATE0)
+    # (the scale goes back to 1 as well: an optimizer stepping outside the fused step — fused_step=False under an outer
+    # GradScaler — must not unscale a second time)
+    if fp16 != state[0] or state[1] != 1.0:
         set_loss_scaling(fp16, 1.0)
 
 #: kernel timing hook (bench.py's roofline pass, run AFTER its timed loop): when a dict, selected launches are bracketed
@@ -162,12 +167,23 @@ def destandardize(r, mean, std):
 
 
 # ------------------------------------------------------------------------------------- dense GEMMs
+#: flag bits of the bf16 GEMM entry points' `accumulate` argument (include/clt_hip.h)
+GEMM_ACCUMULATE, GEMM_ROUND_ACC = 1, 2
+
+
 def _gemm(fn, A, aoff, B, boff, Cm, coff, M, N, K, lda, ldb, ldc, tA, tB, batch=1, sA=0, sB=0, sC=0,
-          bias=None, bias_off=0, sBias=0, accumulate=False):
+          bias=None, bias_off=0, sBias=0, accumulate=False, round_acc=False):
     es = A.element_size()
+    flags = int(bool(accumulate)) | (GEMM_ROUND_ACC if (round_acc and es == 2) else 0)
     _timed_call("gemm", 2.0 * M * N * K * batch, fn, A.data_ptr() + aoff * es, B.data_ptr() + boff * es, Cm.data_ptr() + coff * 4, M, N, K, lda, ldb, ldc,
          int(tA), int(tB), batch, sA, sB, sC, (bias.data_ptr() + bias_off * 4) if bias is not None else None, sBias,
-         int(accumulate), _stream())
+         flags, _stream())
+
+
+#: 16-bit modes: the encoder's product is rounded to the operand format before the fp32 bias is added — the values the
+#: reference's sparsifier sees under torch.autocast (clt.py:157-165: the einsum returns a 16-bit tensor, `+ self.b.to(...)`
+#: promotes it back to fp32); pinned by tests/golden/ac_*_{bf16,fp16}.pt.  False: the fp32 accumulator values (A/B runs).
+AUTOCAST_PRE = True
 
 
 def _fn_for(t):
@@ -176,19 +192,22 @@ def _fn_for(t):
 
 def encoder_fwd(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
     """pre[b,l,:] = xs[b,l,:] @ W[l] + b[l]   (clt.py:157-165).  `Wt` is the feature-major storage of the
-    encoder weight, [L,F,d] (= W.permute(0,2,1)), so both operands are k-contiguous; fp32 or bf16."""
+    encoder weight, [L,F,d] (= W.permute(0,2,1)), so both operands are k-contiguous; fp32 or 16-bit operands (then, with
+    AUTOCAST_PRE, the product is rounded to the operand format before the bias is added, as under the reference's autocast)."""
     Bn, L, d = xs.shape
     F = Wt.shape[1]
     _chk(xs, xs.dtype); _chk(Wt, xs.dtype)
     pre = torch.empty(Bn, L, F, dtype=torch.float32, device=xs.device)
     _gemm(_fn_for(xs), xs, 0, Wt, 0, pre, 0, Bn, F, d, L * d, d, L * F, False, True, batch=L, sA=d, sB=d * F, sC=F,
-          bias=b, sBias=F)
+          bias=b, sBias=F, round_acc=AUTOCAST_PRE)
     return pre
 
 
 def encoder_fwd_out16(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """encoder_fwd with the pre-activations leaving as bf16 [B, L, F] (dense bf16 regime: under the reference's bf16
-    autocast they are a bf16 tensor too).  None when the shape does not qualify for the fast kernel."""
+    """encoder_fwd with the result leaving in the 16-bit operand format [B, L, F] (dense 16-bit regime).  With b = None this is
+    exactly the reference's einsum result under autocast; the consumers (jumprelu_fwd_bf16, jumprelu_loss_bwd_bf16,
+    sparse_build_threshold) then add the fp32 bias in fp32, in autocast's order.  None when the shape does not qualify for
+    the fast kernel."""
     Bn, L, d = xs.shape
     F = Wt.shape[1]
     _chk(xs, op16()); _chk(Wt, op16())
@@ -714,10 +733,14 @@ def jumprelu_loss_bwd(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_
     return sums, dpre, dth, dn
 
 
-def jumprelu_fwd_bf16(x, theta=None):
-    """Dense bf16 regime: JumpReLU (theta=None: ReLU) straight to the GEMM operands.  x: fp32 or bf16 [B, L, F].
+def jumprelu_fwd_bf16(x, theta=None, bias=None):
+    """Dense bf16 regime: JumpReLU (theta=None: ReLU) straight to the GEMM operands.  x: fp32 or bf16 [B, L, F]; bias (fp32
+    [L, F], optional) is added to x first (a 16-bit x then holds the encoder product alone: encoder_fwd_out16(..., None)).
     Returns (feat bf16 [B, L, F], featT bf16 [L, F, B], fired uint8 [L, F])."""
     _chk(x, x.dtype)
+    if bias is not None:
+        _chk(bias)
+        assert bias.numel() == x.shape[1] * x.shape[2]
     assert x.dtype in (torch.float32, op16())
     Bn, L, F = x.shape
     if theta is not None:
@@ -726,15 +749,18 @@ def jumprelu_fwd_bf16(x, theta=None):
     feat = torch.empty(Bn, L, F, dtype=op16(), device=x.device)
     featT = torch.empty(L, F, Bn, dtype=op16(), device=x.device)
     fired = torch.empty(L, F, dtype=torch.uint8, device=x.device)
-    call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype in _DT16), theta.data_ptr() if theta is not None else None, Bn, L * F, feat.data_ptr(),
-         featT.data_ptr(), fired.data_ptr(), _stream())
+    call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype in _DT16), theta.data_ptr() if theta is not None else None,
+         bias.data_ptr() if bias is not None else None, Bn, L * F, feat.data_ptr(), featT.data_ptr(), fired.data_ptr(), _stream())
     return feat, featT, fired
 
 
-def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_tanh, coef_over_BL):
+def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_tanh, coef_over_BL, bias=None):
     """jumprelu_loss_bwd for the dense bf16 regime: returns (sums fp64 [3], dpreT bf16 [L, F, B], dbias fp32 [L, F],
-    dtheta, dnorm) — no fp32 dpre tensor.  pre / dfeat_main: fp32 or bf16."""
+    dtheta, dnorm) — no fp32 dpre tensor.  pre / dfeat_main: fp32 or bf16; bias: as in jumprelu_fwd_bf16."""
     _chk(pre, pre.dtype); _chk(theta); _chk(sq); _chk(dfeat_main, dfeat_main.dtype)
+    if bias is not None:
+        _chk(bias)
+        assert bias.numel() == pre.shape[1] * pre.shape[2]
     assert pre.dtype in (torch.float32, op16()) and dfeat_main.dtype in (torch.float32, op16())
     Bn, L, F = pre.shape
     n = L * F
@@ -744,8 +770,8 @@ def jumprelu_loss_bwd_bf16(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c,
     dth = torch.empty_like(theta)
     dn = torch.empty(n, dtype=torch.float32, device=pre.device)
     ws = workspace(lib.clt_jumprelu_loss_bf16_workspace_bytes(Bn, n), pre.device)
-    call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), int(pre.dtype in _DT16), theta.data_ptr(), sq.data_ptr(),
-         dfeat_main.data_ptr(), int(dfeat_main.dtype in _DT16), float(bandwidth),
+    call("clt_jumprelu_loss_bwd_bf16", pre.data_ptr(), int(pre.dtype in _DT16), theta.data_ptr(),
+         bias.data_ptr() if bias is not None else None, sq.data_ptr(), dfeat_main.data_ptr(), int(dfeat_main.dtype in _DT16), float(bandwidth),
          float(GRAD_SCALE * lam_over_B), float(c), int(use_tanh), float(GRAD_SCALE * coef_over_BL), dpreT.data_ptr(), db.data_ptr(), dth.data_ptr(),
          dn.data_ptr(), sums.data_ptr(), Bn, n, ws.data_ptr(), ws.numel(), _stream())
     return sums, dpreT, db, dth, dn
@@ -851,9 +877,10 @@ def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
     return s
 
 
-def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int) -> SparseLists:
+def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int, bias: Optional[torch.Tensor] = None) -> SparseLists:
     """Lists of JumpReLU(x) (theta [1, L, F]) or ReLU(x) (theta None) straight from the pre-activations x [B, L, F]:
-    entries = positions with x > theta and x > 0 (x fp32, or 16-bit in the active operand format: values widened).  `overflow`
+    entries = positions with x > theta and x > 0 (x fp32, or 16-bit in the active operand format: values widened; a 16-bit
+    x may hold the encoder product alone, the fp32 `bias` [L, F] is then added to the widened values first).  `overflow`
     (device int32 [1]) = 1 when more than `cap` entries exist
     (the lists are then incomplete and the caller takes the dense regime); `total` holds the true count."""
     x16 = x.dtype in _DT16
@@ -863,9 +890,14 @@ def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: 
     if theta is not None:
         _chk(theta)
         assert theta.numel() == L * F
+    if bias is not None:
+        assert x16, "a separate bias only with 16-bit pre-activations"
+        _chk(bias)
+        assert bias.numel() == L * F
     s = _empty_lists(Bn, L, F, int(cap), x.device)
     ws = workspace(lib.clt_sparse_build_workspace_bytes(Bn, L, F), x.device)
-    call("clt_sparse_build_threshold_x16" if x16 else "clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, Bn, L, F, s.cap,
+    extra = ((bias.data_ptr() if bias is not None else None),) if x16 else ()
+    call("clt_sparse_build_threshold_x16" if x16 else "clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, *extra, Bn, L, F, s.cap,
          s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
          s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
          ws.data_ptr(), ws.numel(), _stream())
@@ -1050,7 +1082,7 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     def gemm():
         rc = lib.clt_gemm_bf16_select(xs.data_ptr(), Wt.data_ptr(), Bn, F, d, L * d, d, L * F, L, d, d * F, F,
                                       b.data_ptr() if b is not None else None, F, base + off[0], base + off[7], base + off[8],
-                                      off[9], int(mode == SELECT_LAYER), _stream())
+                                      off[9], int(mode == SELECT_LAYER), GEMM_ROUND_ACC if AUTOCAST_PRE else 0, _stream())
         if rc != 0:
             raise CltError("clt_gemm_bf16_select", rc)
 

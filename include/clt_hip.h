@@ -56,7 +56,13 @@ int clt_destandardize_f32(const float* r_in, const float* mean, const float* std
  * `batch` problems at element strides sA/sB/sC/sBias.  bias may be NULL.  accumulate != 0: C += .
  * f32: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the parity path (rtol 1e-5 vs the fp32 reference).
  * bf16: bf16 operands (uint16_t), fp32 accumulate and fp32 C  (v_mfma_f32_32x32x16_bf16).
+ *       `accumulate` is a flag word there: bit 0 (CLT_GEMM_ACCUMULATE) C +=; bit 1 (CLT_GEMM_ROUND_ACC): the product is
+ *       rounded to the 16-bit operand format BEFORE the fp32 bias is added — torch.autocast's order for the encoder
+ *       (clt.py:157-165: the einsum returns a 16-bit tensor, `+ self.b.to(acts_norm.dtype)` promotes back to fp32), so the
+ *       sparsifier thresholds / selects the values the reference's 16-bit run sees (pinned by tests/golden/ac_*.pt).
  * ------------------------------------------------------------------------------------------- */
+#define CLT_GEMM_ACCUMULATE 1
+#define CLT_GEMM_ROUND_ACC 2
 int clt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb,
                  long ldc, int transA, int transB, int batch, long sA, long sB, long sC,
                  const float* bias, long sBias, int accumulate, void* stream);
@@ -195,12 +201,13 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
  *                           fired[j] = any_r feat > 0 (K12).  theta may be NULL (ReLU).  No fp32 feature tensor.
  *   clt_jumprelu_loss_bwd_bf16: the math of clt_jumprelu_loss_bwd_f32, but d(loss)/d(pre) leaves only as the transposed
  *                           bf16 GEMM operand dpreT[j][r] plus its fp32 column sums dbias[j] (encoder bias gradient). */
-/* x (and dfeat_main) may be held as bf16 (x_bf16 / dfeat_bf16 != 0): what clt_gemm_bf16_nt_out16 leaves — under the
- * reference's bf16 autocast the encoder's pre-activations are bf16 tensors as well (bmm output dtype). */
-int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, int rows, int n, uint16_t* feat, uint16_t* featT,
-                          uint8_t* fired, void* stream);
+/* x (and dfeat_main) may be held as bf16 (x_bf16 / dfeat_bf16 != 0): what clt_gemm_bf16_nt_out16 leaves.  bias (optional,
+ * [n] fp32): added to x in fp32 before anything else — under the reference's autocast the encoder einsum returns a 16-bit
+ * tensor and the fp32 bias is added to it afterwards (clt.py:157-165), so the 16-bit tensor holds the product alone. */
+int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, const float* bias, int rows, int n, uint16_t* feat,
+                          uint16_t* featT, uint8_t* fired, void* stream);
 size_t clt_jumprelu_loss_bf16_workspace_bytes(int rows, int n);
-int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* sq, const void* dfeat_main,
+int clt_jumprelu_loss_bwd_bf16(const void* x, int x_bf16, const float* theta, const float* bias, const float* sq, const void* dfeat_main,
                                int dfeat_bf16, float bandwidth, float lam_over_B, float c, int use_tanh, float coef_over_BL,
                                uint16_t* dpreT, float* dbias, float* dtheta, float* dnorm, double* sums, int rows, int n,
                                void* workspace, size_t ws_bytes, void* stream);
@@ -274,8 +281,10 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
                                    size_t ws_bytes, void* stream);
 /* The same from 16-bit pre-activations (the active operand format: what clt_gemm_bf16_nt_out16 leaves — under the reference's
- * autocast the encoder einsum returns a 16-bit tensor too); entry values are the widened 16-bit values.  F % 4 == 0. */
-int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
+ * autocast the encoder einsum returns a 16-bit tensor too).  bias (optional, [L*F] fp32, 16-byte aligned): the encoder bias,
+ * added in fp32 to the widened value before the comparison (autocast's order, clt.py:165); entry values are widened x (+ bias).
+ * F % 4 == 0. */
+int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, const float* bias, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
                                    size_t ws_bytes, void* stream);
@@ -341,10 +350,11 @@ int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, int ngroups,
  * the shape does not qualify): C = A[M][K] * B[N][K]^T + bias is NOT stored; every element whose key is >= the lower
  * bound of its segment is appended to the candidate list of a selection workspace prepared by stage 0 of
  * clt_select_lists_ext_f32.  ldc / sC define the flat index batch*sC + row*ldc + col of an element.
- * ctl / cand_key / cand_idx / capS: workspace + clt_select_lists_exchange_info(..., flags = 2, which = 0 / 7 / 8 / 9). */
+ * ctl / cand_key / cand_idx / capS: workspace + clt_select_lists_exchange_info(..., flags = 2, which = 0 / 7 / 8 / 9).
+ * flags: CLT_GEMM_ROUND_ACC as in clt_gemm_bf16 (the candidates are then the values the reference's autocast run selects from). */
 int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, long ldc, int batch,
                          long sA, long sB, long sC, const float* bias, long sBias, const uint32_t* ctl, uint32_t* cand_key,
-                         uint32_t* cand_idx, uint32_t capS, int seg_per_batch, void* stream);
+                         uint32_t* cand_idx, uint32_t capS, int seg_per_batch, int flags, void* stream);
 /* Batch-mode selection whose candidates come from clt_gemm_bf16_select.  The lower bound is margin * (the previous
  * step's exact k-th value, prev_T[S] as order-preserving keys: word 0 of the SegState records, exchange info 6).
  * Stage 0 prepares the workspace (then run the GEMM), stages 1..4 as clt_select_lists_sharded_f32 (workspace /

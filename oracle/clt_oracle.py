@@ -34,28 +34,41 @@ Tensor = torch.Tensor
 _OPERAND_DTYPE = None
 _GRAD_SCALE = 1.0
 _ROUND_PRE = False
+_AUTOCAST = False
+_ROUND_ACC = True
 
 
 class operand_rounding:
     """with operand_rounding(torch.bfloat16): ...  — round GEMM operands as the 16-bit MFMA path does.
+    round_acc (default on): the ENCODER product is rounded to the operand format before the fp32 bias is added — the one
+    output rounding of autocast that the build reproduces (CLT_GEMM_ROUND_ACC), because the sparsifier's comparisons and
+    selections are discontinuous in it; every other contraction keeps its fp32 accumulator result in the build.
     grad_scale (fp16 mode, `precision: "16-mixed"`): gradient operands are rounded while multiplied by the loss scale, as
     they are under torch.amp.GradScaler (scale the loss, backward in fp16, unscale the fp32 gradients); an overflow shows
     as inf / NaN in the gradients, which the caller treats as a skipped step.
     round_pre: the encoder's pre-activations are rounded to the operand format as well — what the reference's autocast does
     (under torch.autocast the encoder einsum, model/clt.py:157-165, RETURNS a 16-bit tensor; the sparsifier thresholds those
-    values).  Off: the build's fp32-accumulator pre-activations (selection modes, fp32 list regime)."""
+    values).  Off: the build's fp32-accumulator pre-activations (selection modes, fp32 list regime).
+    autocast: restate torch.autocast itself rather than the build's 16-bit mode — every contraction (forward AND its
+    autograd backward) also RETURNS a 16-bit tensor: the encoder result is rounded and the fp32 bias added afterwards
+    (model/clt.py:157-165: `pre_actvs + self.b.to(acts_norm.dtype)` promotes back to fp32), each target layer's
+    reconstruction is rounded before the bias (clt.py:337-343), each weight gradient and each per-target-layer feature
+    gradient is rounded (carrying the loss scale) before it is accumulated in fp32.  Pinned by the reference's own autocast
+    runs (tests/golden/ac_*_{bf16,fp16}.pt, tests/test_oracle_golden.py:test_autocast_restatement_matches_reference)."""
 
-    def __init__(self, dtype, grad_scale: float = 1.0, round_pre: bool = False):
+    def __init__(self, dtype, grad_scale: float = 1.0, round_pre: bool = False, autocast: bool = False, round_acc: bool = True):
         self.dtype, self.grad_scale, self.round_pre = dtype, float(grad_scale), bool(round_pre)
+        self.autocast, self.round_acc = bool(autocast), bool(round_acc)
 
     def __enter__(self):
-        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE
-        self.old = (_OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE)
-        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE = self.dtype, self.grad_scale, self.round_pre
+        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE, _AUTOCAST, _ROUND_ACC
+        self.old = (_OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE, _AUTOCAST, _ROUND_ACC)
+        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE, _AUTOCAST, _ROUND_ACC = (self.dtype, self.grad_scale, self.round_pre,
+                                                                          self.autocast, self.round_acc)
 
     def __exit__(self, *a):
-        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE
-        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE = self.old
+        global _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE, _AUTOCAST, _ROUND_ACC
+        _OPERAND_DTYPE, _GRAD_SCALE, _ROUND_PRE, _AUTOCAST, _ROUND_ACC = self.old
 
 
 def _q(t: Tensor) -> Tensor:
@@ -67,6 +80,16 @@ def _qg(t: Tensor) -> Tensor:
     if _OPERAND_DTYPE is None:
         return t
     return (t * _GRAD_SCALE).to(_OPERAND_DTYPE).to(t.dtype) / _GRAD_SCALE
+
+
+def _qo(t: Tensor) -> Tensor:
+    """A forward contraction's result: 16-bit under the autocast restatement, the fp32 accumulator otherwise."""
+    return _q(t) if _AUTOCAST else t
+
+
+def _qgo(t: Tensor) -> Tensor:
+    """A backward contraction's result (a gradient, carrying the loss scale), same rule."""
+    return _qg(t) if _AUTOCAST else t
 
 
 # --------------------------------------------------------------------------------------------
@@ -103,19 +126,21 @@ def encoder_fwd(xs: Tensor, W: Tensor, b: Tensor) -> Tensor:
     B, L, d = xs.shape
     pre = torch.empty(B, L, W.shape[2], dtype=xs.dtype)
     for l in range(L):
-        pre[:, l] = _q(xs[:, l]) @ _q(W[l]) + b[l]
+        prod = _q(xs[:, l]) @ _q(W[l])
+        pre[:, l] = (_q(prod) if (_AUTOCAST or _ROUND_ACC) else prod) + b[l]
     return _q(pre) if _ROUND_PRE else pre
 
 
 def encoder_fwd_layer(x: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
     """Inference path of ONE layer, model/clt.py:134-145: x [batch, seq, d_acts] -> [batch, seq, d_features]."""
-    return _q(x) @ _q(W[layer]) + b[layer]
+    prod = _q(x) @ _q(W[layer])
+    return (_q(prod) if (_AUTOCAST or _ROUND_ACC) else prod) + b[layer]
 
 
 def encoder_bwd(xs: Tensor, dpre: Tensor) -> Tuple[Tensor, Tensor]:
     """dW[l] = xs[:,l]^T @ dpre[:,l];  db = sum_b dpre.  (No dx: the batch does not require grad.)"""
     L = xs.shape[1]
-    dW = torch.stack([_q(xs[:, l]).T @ _qg(dpre[:, l]) for l in range(L)])
+    dW = torch.stack([_qgo(_q(xs[:, l]).T @ _qg(dpre[:, l])) for l in range(L)])
     return dW, dpre.sum(dim=0)
 
 
@@ -231,7 +256,7 @@ def crosslayer_decoder_fwd(feat: Tensor, Ws: List[Tensor], b: Tensor) -> Tensor:
     d = b.shape[1]
     r = torch.empty(B, L, d, dtype=feat.dtype)
     for l in range(L):
-        r[:, l] = _q(feat[:, : l + 1].reshape(B, -1)) @ _q(Ws[l].reshape(-1, d))
+        r[:, l] = _qo(_q(feat[:, : l + 1].reshape(B, -1)) @ _q(Ws[l].reshape(-1, d)))
     return r + b
 
 
@@ -243,15 +268,15 @@ def crosslayer_decoder_bwd(feat: Tensor, Ws: List[Tensor], g: Tensor) -> Tuple[T
     for l in range(L):
         dW = torch.empty_like(Ws[l])
         for lp in range(l + 1):
-            dfeat[:, lp] += _qg(g[:, l]) @ _q(Ws[l][lp]).T
-            dW[lp] = _q(feat[:, lp]).T @ _qg(g[:, l])
+            dfeat[:, lp] += _qgo(_qg(g[:, l]) @ _q(Ws[l][lp]).T)
+            dW[lp] = _qgo(_q(feat[:, lp]).T @ _qg(g[:, l]))
         dWs.append(dW)
     return dfeat, dWs, g.sum(dim=0)
 
 
 def plt_decoder_fwd(feat: Tensor, W: Tensor, b: Tensor) -> Tensor:
     L = feat.shape[1]
-    return torch.stack([_q(feat[:, l]) @ _q(W[l]) for l in range(L)], dim=1) + b
+    return torch.stack([_qo(_q(feat[:, l]) @ _q(W[l])) for l in range(L)], dim=1) + b
 
 
 def plt_decoder_fwd_layer(feat: Tensor, W: Tensor, b: Tensor, layer: int) -> Tensor:
@@ -271,8 +296,8 @@ def crosslayer_decoder_fwd_layer(feat: Tensor, Ws: List[Tensor], b: Tensor, laye
 
 def plt_decoder_bwd(feat: Tensor, W: Tensor, g: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     L = feat.shape[1]
-    dfeat = torch.stack([_qg(g[:, l]) @ _q(W[l]).T for l in range(L)], dim=1)
-    dW = torch.stack([_q(feat[:, l]).T @ _qg(g[:, l]) for l in range(L)])
+    dfeat = torch.stack([_qgo(_qg(g[:, l]) @ _q(W[l]).T) for l in range(L)], dim=1)
+    dW = torch.stack([_qgo(_q(feat[:, l]).T @ _qg(g[:, l])) for l in range(L)])
     return dfeat, dW, g.sum(dim=0)
 
 

@@ -118,7 +118,8 @@ def gpu_selection_ties(rank, world):
     xl = shard.slice_features(x, 2).contiguous().cuda()
     for k in (5, 100, 300):
         S = ops.select_lists_sharded(xl, k, ops.SELECT_BATCH, shard, torch.zeros(1, device="cuda"), 0.1, None)
-        assert S.tie_radix, "expected the tie-radix form (tie lists overflow)"
+        # (one rank: the kernels rank ties by the index radix select inside stage 4 already, no tie lists to overflow)
+        assert S.tie_radix or world == 1, "expected the tie-radix form (tie lists overflow)"
         ref = O.batch_topk_fwd(x, k)[0]
         assert torch.equal(ops.sparse_scatter_dense(S, S.csc_val).cpu(), shard.slice_features(ref, 2)), f"tie radix batch k={k}"
         S = ops.select_lists_sharded(xl, k, ops.SELECT_LAYER, shard, torch.zeros(L, device="cuda"), 0.1, None)
@@ -188,6 +189,53 @@ def gpu_bf16_fused_sharded(rank, world):
             # Adam's first steps are sign-like: a bf16 rounding flip of one gathered g element moves a weight by a
             # fraction of lr (same absolute allowance as the golden-trajectory tests: 0.3 * lr)
             assert_close(p, ref, 1e-4, 0.3 * 1e-3, f"{kind} param {k}")
+
+
+def gpu_fp16_overflow_on_one_shard(rank, world):
+    """`precision: "16-mixed"` under feature sharding: an fp16 overflow that only ONE rank's shard produces (a decoder weight
+    too large for fp16 in the last rank's slice: the 16-bit shadow cast raises that rank's flag) must skip the step on EVERY
+    rank — same loss scale, same skip count, untouched parameters and optimizer state, replicated decoder.b still identical —
+    and the next, clean step trains on every rank."""
+    from crosslayer_transcoder_amd import precision
+    from crosslayer_transcoder_amd.parallel import FeatureShard, shard_module
+    from tests.build_cases import build_module
+    B, L, d, F = 512, 3, 128, 1024
+    g = torch.Generator().manual_seed(17)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(2)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "batchtopk", "k": 8, "e": 0.1},
+                    "loss": {"kind": "base"}}, "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
+            "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+    mod = build_module(case, "cuda:0")
+    shard = FeatureShard(F, keep_single=KEEP_SINGLE)
+    shard_module(mod, shard)
+    opt = mod.configure_optimizers()
+    W2 = mod.model.decoder.weights()[2]
+    keep = W2[0, 0, 0].clone()
+    if rank == world - 1:
+        with torch.no_grad():
+            W2[0, 0, 0] = 1e6
+    before = {k: p.detach().clone() for k, p in mod.model.named_parameters()}
+    with precision("16-mixed"):
+        mod.fused_train_step(batches[0].cuda(), 0, opt)
+        assert mod.loss_scaler.scale == 32768.0 and mod.loss_scaler.skipped_steps == 1, \
+            f"rank {rank}: scale {mod.loss_scaler.scale}, skipped {mod.loss_scaler.skipped_steps}"
+        for k, p in mod.model.named_parameters():
+            assert torch.equal(p.detach(), before[k]), f"rank {rank}: the skipped step changed {k}"
+            assert int(opt.state.get(p, {}).get("step", 0)) == 0, f"rank {rank}: {k} counted a step"
+        with torch.no_grad():
+            W2[0, 0, 0] = keep
+        loss = mod.fused_train_step(batches[1].cuda(), 1, opt)
+        assert torch.isfinite(loss) and mod.loss_scaler.scale == 32768.0 and mod.loss_scaler.skipped_steps == 1
+        moved = sum(int(not torch.equal(p.detach(), before[k])) for k, p in mod.model.named_parameters())
+        assert moved == len(before), f"rank {rank}: only {moved} of {len(before)} parameters trained after the skipped step"
+    b = mod.model.decoder.b.detach().clone()
+    ref = b.clone()
+    shard.all_reduce_min(ref)
+    assert torch.equal(b, ref), "decoder.b diverged between ranks after a one-shard overflow"
 
 
 def gpu_save_sharded(rank, world):
@@ -442,6 +490,7 @@ def main():
             gpu_selection_ties(rank, world)
             gpu_list_capacity_overflow(rank, world)
             gpu_bf16_fused_sharded(rank, world)
+            gpu_fp16_overflow_on_one_shard(rank, world)
             gpu_save_sharded(rank, world)
             from crosslayer_transcoder_amd import engine
             for name in args.cases.split(","):

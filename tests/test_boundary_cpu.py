@@ -161,3 +161,43 @@ def test_forward_ops_are_registered_with_the_dispatcher():
     import pytest
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.clt_hip.relu(torch.zeros(4, 4))
+
+
+def test_fp16_fused_step_advances_the_lightning_progress_hooks(monkeypatch):
+    """`precision: "16-mixed"` with fused_step: the library's own loss scaling steps the RAW FusedAdam (an outer GradScaler
+    would unscale a second time), so Lightning's manual-optimisation progress — trainer.global_step is the count of
+    LightningOptimizer._on_after_step calls — is advanced by calling the wrapper's _on_before_step / _on_after_step hooks
+    around the raw step.  Lightning is not installed here ("parity unpinned" for the trainer integration): the wrapper is a
+    stub with LightningOptimizer's attribute names; the engine call is stubbed out (no GPU in this test)."""
+    import crosslayer_transcoder_amd as cta
+    from crosslayer_transcoder_amd.model import BatchTopK
+    from crosslayer_transcoder_amd.model.clt_lightning import CrossLayerTranscoderModule
+    from crosslayer_transcoder_amd.precision import LossScaler
+    mod = CrossLayerTranscoderModule(model=_model(BatchTopK(k=2, e=0.1)))
+    raw = mod.configure_optimizers()
+    calls = []
+
+    class Wrapper:                       # lightning.pytorch.core.optimizer.LightningOptimizer's surface
+        optimizer = raw
+
+        def _on_before_step(self):
+            calls.append("before")
+
+        def _on_after_step(self):
+            calls.append("after")
+
+        def step(self, *a, **k):
+            raise AssertionError("the wrapper's step() would route through the precision plugin's GradScaler")
+
+    monkeypatch.setattr(mod, "compute_step", lambda *a, **k: {"grads": {}, "loss": torch.tensor(1.0)})
+    monkeypatch.setattr(raw, "step", lambda *a, **k: calls.append("raw-step"))
+    mod.loss_scaler = LossScaler()
+    try:
+        cta.set_precision("16-mixed")
+        batch = torch.zeros(4, 2, 2, 110)
+        for i in range(3):
+            mod.fused_train_step(batch, i, raw, None, stepper=Wrapper())
+    finally:
+        cta.set_precision("32")
+    assert calls == ["before", "raw-step", "after"] * 3
+    assert mod.loss_scaler.growth_tracker == 3 and mod.loss_scaler.skipped_steps == 0

@@ -165,3 +165,49 @@ def test_debug_yaml_in_16_mixed_follows_the_fp32_curve(tmp_path, golden):
         assert mod.loss_scaler.skipped_steps == 0 and mod.loss_scaler.scale == 65536.0
     finally:
         set_precision("32")
+
+
+def test_fp16_gemm_epilogues_raise_the_overflow_flag():
+    """The GEMM translation units hold the loss scaler's state too: an fp16 store epilogue (clt_gemm_bf16_nt_out16) or the
+    rounded encoder product (CLT_GEMM_ROUND_ACC, fast and generic kernels) that overflows fp16 raises the flag."""
+    from crosslayer_transcoder_amd import ops, precision
+    g = torch.Generator().manual_seed(3)
+    Bn, L, d, F = 256, 2, 64, 256
+    xs = torch.randn(Bn, L, d, generator=g).cuda()
+    W = torch.randn(L, F, d, generator=g).cuda()
+    b = torch.zeros(L, F).cuda()
+    with precision("16-mixed"):
+        flag = ops.inf_flag(xs.device)
+        for scale, want in ((1.0, 0), (300.0, 1)):          # |x| * 300 * |w| * 300 summed over 64 terms >> 65504
+            x16, w16 = ops.cast_bf16(xs * scale), ops.cast_bf16(W * scale)
+            for call in (lambda: ops.encoder_fwd_out16(x16, w16, b), lambda: ops.encoder_fwd(x16, w16, b),
+                         lambda: ops.encoder_fwd(x16[:100].contiguous(), w16[:, :100].contiguous(), b[:, :100].contiguous())):   # (generic kernel)
+                flag.zero_()
+                ops.set_loss_scaling(True, 65536.0, flag)
+                assert call() is not None
+                assert int(flag.item()) == want, f"scale {scale}: flag {int(flag.item())}"
+    ops.set_loss_scaling(False)
+
+
+def test_fp16_overflowing_pre_activations_skip_the_step():
+    """A JumpReLU module whose 16-bit pre-activation tensor overflows fp16 in the encoder GEMM's store epilogue: the step is
+    skipped as a whole (nothing changes, step counts given back) and the loss scale halves."""
+    import crosslayer_transcoder_amd as cta
+    from crosslayer_transcoder_amd import precision
+    from tests.build_cases import build_module
+    case = _case("plt", "jumprelu", "jumprelu")
+    case["init_params"]["encoder.W"] = case["init_params"]["encoder.W"] * 3e5        # pre ~ N(0, (0.3 * 3e5)^2): far beyond 65504
+    batch = case["batches"][0].cuda()
+    try:
+        with precision("16-mixed"):
+            mod = build_module(case)
+            mod.log_metrics_every = 0
+            opt, _ = mod.attach_optimizers()
+            before = {k: p.detach().clone() for k, p in mod.model.named_parameters()}
+            mod.training_step(batch, 0)
+            assert mod.loss_scaler.skipped_steps == 1 and mod.loss_scaler.scale == 32768.0
+            for k, p in mod.model.named_parameters():
+                assert torch.equal(p.detach(), before[k]), f"skipped step changed {k}"
+                assert int(opt.state.get(p, {}).get("step", 0)) == 0, k
+    finally:
+        cta.set_precision("32")

@@ -5,7 +5,7 @@ _inference_forward (topk.py:49-51 per-row top-k; :71-74 / :104-107 threshold com
 import pytest
 import torch
 
-from tests.golden_cases import assert_close
+from tests.golden_cases import assert_close, assert_close_rounded
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,9 @@ def test_forward_layer_paths_bf16():
     with precision("bf16-mixed"), O.operand_rounding(torch.bfloat16):
         for layer in range(L):
             want = O.encoder_fwd_layer(x, enc.W.detach().cpu(), enc.b.detach().cpu(), layer)
-            assert_close(enc(x.cuda(), layer=layer), want, 1e-4, 1e-5 * float(want.abs().max()), "encoder bf16")
+            # (the encoder product is rounded to bf16 before the bias joins it — autocast's order: summation-order noise of the
+            # fp32 accumulator flips a few of those roundings)
+            assert_close_rounded(enc(x.cuda(), layer=layer), want, 2.0 ** -7, 1e-4, 1e-5 * float(want.abs().max()), what="encoder bf16")
             fc = f4[:, :, :layer + 1].contiguous()
             want = O.crosslayer_decoder_fwd_layer(fc, [w.detach().cpu() for w in clt.weights()], clt.b.detach().cpu(), layer)
             assert_close(clt(fc.cuda(), layer=layer), want, 1e-4, 1e-5 * float(want.abs().max()), "crosslayer decoder bf16")

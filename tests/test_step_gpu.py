@@ -439,9 +439,9 @@ def test_threshold_lists_bf16_step(dec_kind, nl_kind):
         assert 0 < int(out["lists"].total) < 0.05 * batch.shape[0] * 3 * 512
     c = dict(case["cfg"]); c["loss"] = dict(c["loss"], step_frac=0.5)
     buf = {"last_active": case["last_active0"].clone()}
-    # (JumpReLU module: the list build thresholds the 16-bit pre-activations the encoder GEMM leaves — as the reference's
-    # autocast does; ReLU + base loss keeps the fp32 accumulator values)
-    with O.operand_rounding(torch.bfloat16, round_pre=nl_kind == "jumprelu"):
+    # (the pre-activations are the encoder product rounded to bf16 plus the fp32 bias — autocast's order, the oracle's
+    # default round_acc — whether they pass through the 16-bit tensor of the JumpReLU module's regime or stay fp32)
+    with O.operand_rounding(torch.bfloat16):
         ref = O.training_step(batch, case["init_params"], O.standardizer_init(batch), c, buf)
     assert_close(out["loss"], ref["loss"], 2e-3, 1e-6, "loss")
     assert torch.equal(out["features"].cpu() > 0, ref["features"] > 0) or \
