@@ -88,6 +88,29 @@ def cpu_model_name():
     return "unknown CPU"
 
 
+def physical_cores():
+    """Physical cores of the host (the CPU leg's thread count is torch's; hyper-threads are not cores)."""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:                                  # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
+
+
+def kernel_source_digest():
+    """sha256 of the source the dominant kernel is built from: profiles/pmc_traffic.json carries the digest (and the commit)
+    it was measured on, and a stale measurement is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sparse.hip", "lists_common.h", "common.h"):
+        with open(os.path.join(ROOT, "crosslayer_transcoder_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args):
     """The CPU oracle (a restatement of the reference's fp32 dense path) on a bounded sample of the same workload
     (SURVEY §8d): full model shape, batch of `--cpu-batch` tokens, loss + gradients + Adam; one warm-up step, then the
@@ -121,8 +144,8 @@ def cpu_baseline(args):
     med = statistics.median(times)
     return {"value": Bc / med, "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"CPU oracle (restatement of the reference's dense fp32 step: loss+grads+Adam), full model shape L={L} d={d} "
-                      f"F={F}, batch {Bc} tokens, {threads} torch threads on {cpu_model_name()}; 1 warm-up step, median of "
-                      f"{len(times)} timed step(s) = {med:.1f} s"}
+                      f"F={F}, batch {Bc} tokens, {threads} torch threads on {cpu_model_name()} ({physical_cores()} physical cores, "
+                      f"{os.cpu_count()} logical, on the host); 1 warm-up step, median of {len(times)} timed step(s) = {med:.1f} s"}
 
 
 def roofline(timing, mod, args, world):
@@ -167,11 +190,17 @@ def roofline(timing, mod, args, world):
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from the rocprofv3 --pmc passes
     default_workload = (args.batch, args.features, args.layers, args.d_acts, args.k, args.nonlinearity, args.decoder, args.aux,
                         world) == (4096, 32768, 12, 768, 16, "batchtopk", "clt", False, 1)
+    traffic_of = None
     if os.path.exists(tf) and default_workload:       # (the PMC passes were taken on the headline configuration)
         with open(tf) as fh:
-            traffic = json.load(fh).get("row_pass_bytes_per_launch")
+            rec = json.load(fh)
+        if rec.get("kernel_source_digest") == kernel_source_digest():      # measured on THIS kernel source, else not reported
+            traffic = rec.get("row_pass_bytes_per_launch")
+            traffic_of = rec.get("commit")
+        else:
+            traffic_of = "stale: profiles/pmc_traffic.json was measured on another version of csrc/sparse.hip (scripts/gpu_pmc.sh)"
     return {"bound": "hbm", "kernel": "row_pass_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": len(ev),
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at": traffic_of, "launches": len(ev),
             "avg_launch_us": ms * 1e3 / len(ev), "bytes_per_launch": nbytes / len(ev)}
 
 
@@ -212,7 +241,9 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=N_BATCHES,
                     help="resident synthetic batches cycled through the steps (fewer only where HBM is short: config 5 on one GPU)")
     ap.add_argument("--cpu-batch", type=int, default=256)
-    ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU-oracle time after which no further step starts")
+    ap.add_argument("--cpu-budget", type=float, default=150.0,
+                    help="seconds of CPU-oracle time after which no further step starts (1 warm-up + 3 timed steps of ~21 s "
+                         "each at the default sample: SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 

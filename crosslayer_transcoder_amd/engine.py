@@ -17,15 +17,13 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
-import os
-
 import torch
 
 from . import ops
 from .model.clt import CrosslayerDecoder, Decoder
 from .model.jumprelu import JumpReLU, ReLU
 from .model.topk import BatchTopK, PerLayerBatchTopK, PerLayerTopK
-from .precision import LossScaler, get_precision, mixed16
+from .precision import LossScaler, ab_check, ab_switch, get_precision, mixed16
 
 
 def _op(t):
@@ -96,25 +94,25 @@ SELECT_MARGIN = 0.9
 #: allows (device-side peak-hold of |T_t / T_{t-1} - 1|, clt_select_lists_ext_f32's drift state): fewer candidates in the epilogue
 ADAPTIVE_SELECT_MARGIN = True
 #: queue the decoder's gather forward before the host reads the fused selection's outcome flag
-SPECULATIVE_FORWARD = os.environ.get("CLT_SPEC_FWD", "1") != "0"
-#: streams the decoder's weight passes alternate over when the matrices are small (CLT_ROWPASS_STREAMS=1: off, for A/B runs)
-ROW_PASS_STREAMS = int(os.environ.get("CLT_ROWPASS_STREAMS", "2"))
+SPECULATIVE_FORWARD = True
+#: streams the decoder's weight passes alternate over when the matrices are small (CLT_AB=rowpass_streams=1: off, for A/B runs)
+ROW_PASS_STREAMS = ab_switch("rowpass_streams", 2)
 ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below which a pass is "short"
-#: short passes of one layer group in one launch (CLT_GROUP_ROW_PASSES=0: off, for A/B runs)
-GROUP_ROW_PASSES = os.environ.get("CLT_GROUP_ROW_PASSES", "1") != "0"
+#: short passes of one layer group in one launch (CLT_AB=group_row_passes=0: off, for A/B runs)
+GROUP_ROW_PASSES = bool(ab_switch("group_row_passes", 1))
 _side_stream = ops._side_stream          # (one side stream per device, shared with ops.clt_decoder_dgrad_kseg)
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
 COMPACT_AUX_MAX_SHARE = 0.5
-COMPACT_AUX_FUSED_OPERANDS = os.environ.get("CLT_AUX_FUSED_OPS", "1") != "0"     # (0: separate cast / transpose / mask passes)
-COMPACT_AUX_GEMM_COLUMNS = os.environ.get("CLT_AUX_GEMM_COLS", "1") != "0"       # (0: gather them from `pre`, for A/B runs)
+COMPACT_AUX_FUSED_OPERANDS = True     # (False: separate cast / transpose / mask passes; A/B verdict r02: 35.0 -> 32.7 ms)
+COMPACT_AUX_GEMM_COLUMNS = True       # (False: gather the dead columns from `pre`)
 #: dense bf16 regime of the JumpReLU module: the sparsifier forward and the loss backward write the bf16 GEMM operands
 #: (features, features^T, dpre^T) directly — no fp32 feature / dpre tensors, no separate cast / transpose / column-sum passes
-#: dense bf16 JumpReLU regime: pre-activations / feature gradient stored as bf16 (CLT_DENSE_BF16_ACT=0: fp32, for A/B runs)
-DENSE_BF16_ACTIVATIONS = os.environ.get("CLT_DENSE_BF16_ACT", "1") != "0"
-#: ... and in the steps that build activation lists from them (CLT_LIST_BF16_ACT=0: fp32 pre-activations there, for A/B runs)
-LIST_BF16_ACTIVATIONS = os.environ.get("CLT_LIST_BF16_ACT", "1") != "0"
+#: dense bf16 JumpReLU regime: pre-activations / feature gradient stored as bf16 (CLT_AB=dense_bf16_act=0: fp32, for A/B runs)
+DENSE_BF16_ACTIVATIONS = bool(ab_switch("dense_bf16_act", 1))
+#: ... and in the steps that build activation lists from them (CLT_AB=list_bf16_act=0: fp32 pre-activations there)
+LIST_BF16_ACTIVATIONS = bool(ab_switch("list_bf16_act", 1))
 FUSE_DENSE_JUMPRELU = True
 #: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
 FUSE_WEIGHT_PREP = True
@@ -134,9 +132,10 @@ PIPELINE_EXCHANGE = True
 LIST_MAX_DENSITY = 1.0 / 512
 #: list regime with the fused optimizer: the Adam row passes write each updated decoder row's squared length, which is
 #: the next step's dec_norms (CLT at G32: 78 row_sqnorm launches = 1.36 ms of 34.8 per step otherwise)
-ROW_PASS_KEEPS_NORMS = os.environ.get("CLT_ROW_PASS_NORMS", "1") != "0"
+ROW_PASS_KEEPS_NORMS = True
 #: after a step whose density was above the break-even, the next attempt is made this many steps later (doubling, capped)
 LIST_RETRY_FIRST, LIST_RETRY_MAX = 8, 512
+ab_check()                  # (every switch of the package is registered by now: ops.py's and the ones above)
 
 
 def _encoder_operand(enc):

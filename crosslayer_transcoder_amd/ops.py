@@ -13,7 +13,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from ._lib import CltError, call, lib
-from .precision import operand_dtype as op16
+from .precision import ab_switch, operand_dtype as op16
 
 _ws = {}
 _DT16 = (torch.bfloat16, torch.float16)
@@ -98,7 +98,7 @@ def _stream():
 
 #: K-segmented feature-gradient GEMMs of a cross-layer decoder over two streams when their tile count leaves a short last
 #: round (see clt_decoder_dgrad_kseg); 1 = one stream
-KSEG_DGRAD_STREAMS = int(os.environ.get("CLT_KSEG_DGRAD_STREAMS", "2"))
+KSEG_DGRAD_STREAMS = ab_switch("kseg_dgrad_streams", 2)
 _side_streams = {}
 
 

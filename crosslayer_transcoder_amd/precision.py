@@ -77,3 +77,32 @@ class LossScaler:
 
     def load_state_dict(self, sd):
         self.scale, self.growth_tracker = float(sd["scale"]), int(sd["growth_tracker"])
+
+
+# ---- A/B switches -------------------------------------------------------------------------------------------------
+def _parse_ab():
+    """CLT_AB="name=value,name=value": the ONE environment variable the package reads for same-box A/B runs of code paths
+    whose default is settled (scripts/gpu_*_ab.sh).  Unknown names raise at import, so a typo cannot silently measure the
+    default twice."""
+    import os
+    out = {}
+    for item in filter(None, (t.strip() for t in os.environ.get("CLT_AB", "").split(","))):
+        name, _, val = item.partition("=")
+        out[name.strip()] = val.strip() or "1"
+    return out
+
+
+_AB = _parse_ab()
+_AB_KNOWN = set()
+
+
+def ab_switch(name: str, default: int) -> int:
+    """Integer value of switch `name` from CLT_AB, else `default`."""
+    _AB_KNOWN.add(name)
+    return int(_AB.get(name, default))
+
+
+def ab_check():
+    unknown = set(_AB) - _AB_KNOWN
+    if unknown:
+        raise ValueError(f"CLT_AB names unknown switches {sorted(unknown)}; known: {sorted(_AB_KNOWN)}")
