@@ -77,6 +77,34 @@ def build(args, device, world=1):
     return mod
 
 
+def apply_skew(mod, args, seed=7):
+    """--skew zipf: per-feature encoder-bias offsets under which the firing frequency of a layer's features follows a Zipf law
+    (p_r ~ 1 / r, clamped at 0.5, summing to k per token and layer as in the uniform workload — BatchTopK keeps the total at
+    k*B*L by itself), i.e. a handful of features active in >= 10 % of the tokens and a long tail of rare ones: what real
+    dictionaries look like, and what the one-wave-per-row weight pass is worst at.  With standardized inputs the pre-activation
+    of feature f is ~ N(0, |W_f|^2); b_f moves its exceedance probability of the uniform workload's threshold to p_f."""
+    L, F, k = args.layers, args.features, args.k
+    r = torch.arange(1, F + 1, dtype=torch.float64)
+    c = k / (1.0 / r).sum()
+    for _ in range(60):                                   # rescale until the clamped frequencies sum to k again
+        q = (c / r).clamp(max=0.5)
+        c = c * k / q.sum()
+    q = (c / r).clamp(max=0.5)
+    z = lambda p: (2.0 ** 0.5) * torch.erfinv(1.0 - 2.0 * p)  # noqa: E731  (upper-tail normal quantile)
+    enc = mod.model.encoder
+    sig = enc.Wt.detach().double().norm(dim=2).cpu()      # [L, F]
+    g = torch.Generator().manual_seed(seed)
+    b = torch.empty(L, F, dtype=torch.float64)
+    for l in range(L):
+        perm = torch.randperm(F, generator=g)
+        ql = torch.empty(F, dtype=torch.float64)
+        ql[perm] = q
+        b[l] = sig[l].mean() * z(torch.tensor(k / F, dtype=torch.float64)) - sig[l] * z(ql)
+    with torch.no_grad():
+        enc.b.copy_(b.float().to(enc.b.device))
+    return {"law": "zipf", "features_ge_10pct_per_layer": int((q >= 0.1).sum()), "max_frequency": float(q.max())}
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -240,6 +268,8 @@ def parse_args():
                     help="fused encoder+select: candidate bound = margin x last step's k-th value (default: engine.SELECT_MARGIN)")
     ap.add_argument("--distinct-batches", type=int, default=N_BATCHES,
                     help="resident synthetic batches cycled through the steps (fewer only where HBM is short: config 5 on one GPU)")
+    ap.add_argument("--skew", default="none", choices=["none", "zipf"],
+                    help="zipf: heavy-tailed feature firing frequencies through encoder-bias offsets (apply_skew); not the headline")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=150.0,
                     help="seconds of CPU-oracle time after which no further step starts (1 warm-up + 3 timed steps of ~21 s "
@@ -310,6 +340,7 @@ def main():
         import crosslayer_transcoder_amd.engine as _engine
         _engine.SELECT_MARGIN = args.select_margin
     mod = build(args, device, world)
+    skew = apply_skew(mod, args) if args.skew == "zipf" and world == 1 else None
     opt, sched = mod.attach_optimizers()
     A = synth_target_map(args.layers, args.d_acts, device)
     batches = [synth_batch(args.batch, args.layers, args.d_acts, device, seed=i, A=A) for i in range(args.distinct_batches)]
@@ -391,6 +422,13 @@ def main():
                        mod.last_step.get("lists")),
                    "loss": float(mod.last_step["loss"])},
     }
+    if skew is not None:
+        S_ = mod.last_step.get("lists")
+        if S_ is not None:
+            lens = (S_.col_start[1:] - S_.col_start[:-1]).long()
+            skew.update(longest_column=int(lens.max()), hot_columns=int((lens > ops.HOT_MIN_LEN).sum()) if ops.HOT_MIN_LEN > 0 else None,
+                        entries_in_hot_columns=(float(lens[lens > ops.HOT_MIN_LEN].sum()) / max(int(lens.sum()), 1)) if ops.HOT_MIN_LEN > 0 else None)
+        line["config"]["skew"] = skew
     if rank == 0:
         line["roofline"] = roofline(timing, mod, args, world)
         if world == 1 and not args.no_cpu_baseline:

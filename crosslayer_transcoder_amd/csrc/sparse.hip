@@ -133,6 +133,9 @@ struct RowPassArgs {
     // optional (one wave per row, i.e. d <= 1024): squared length of the UPDATED row r to sq_out[r] — next step's dec_norms
     // without another read of the matrix; same per-lane order and wave reduction as row_sqnorm_kernel
     float* sq_out;
+    // > 0: rows whose (first) list holds more than this many entries are left to row_pass_hot_kernel (heavy-tailed feature
+    // frequencies: a feature active in 10 % of the tokens is a 400-entry list, which one wave would walk alone)
+    int hot_min_len;
 };
 
 // CW = waves per weight row.  CW == 1: four rows per 256-thread block, one wave each (d <= 1024 floats per wave with
@@ -187,6 +190,223 @@ __device__ __forceinline__ void rp_st2(uint16_t* q, uint32_t a, uint32_t b) {
 }
 // SQ: also write the updated row's squared length (a.sq_out) — its own instantiation: compiled into the common kernel the
 // few extra instructions cost the headline launch 20 us (830 -> 851, register allocation of the whole body moved)
+// The entries [p, pend) of one list of column `col` (a whole column, or one wave's segment of a hot column): gradient sums into
+// g, dots written, coefficient sum into csum.  p0 = first entry of the column (parity of the CW > 1 dot exchange).
+template <int NT, bool VEC, int CW, bool F16>
+__device__ __forceinline__ void row_pass_walk(const RowPassArgs& a, const int pass, const int col, const int layer, const int lane, const int wave,
+                                              const int cb, uint32_t p, const uint32_t pend, const uint32_t p0, const float (&wv)[NT][VEC ? 4 : 1],
+                                              float (&g)[NT][VEC ? 4 : 1], float& csum, float (*shdot)[CW]) {
+    constexpr int W = VEC ? 4 : 1;
+    const long srs = (long)a.L * a.d;
+    const int32_t* tk = pass ? a.tok2 : a.tok;
+    const float* cf = pass ? a.coef2 : a.coef;
+    const float* src = (pass ? a.src2 : a.src) + (a.src_bf16 ? 0 : (long)layer * a.d);
+    const uint16_t* srch = reinterpret_cast<const uint16_t*>(pass ? a.src2 : a.src) + (long)layer * a.d;
+    float* dout = pass ? a.dot_out2 : a.dot_out;
+    const long dstride = pass ? a.dot_stride2 : a.dot_stride;
+#if RP_HU > 1
+    // Columns with several entries (the JumpReLU lists' tens of tokens per feature): RP_HU entries' source rows are
+    // requested together and then accumulated in list order — the same sums, a fraction of the serialised round trips.
+    if constexpr (VEC && CW == 1) if (a.src_bf16) {
+        auto batch = [&](auto nu) {                     // the next NU entries: all source-row loads first, then the sums in list order
+            constexpr int NU = decltype(nu)::value;
+            float cvs[NU];
+            ushort4 hh[NU][NT];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                cvs[u] = cf[p + u];
+                const uint16_t* rowh = srch + (long)tk[p + u] * srs;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int o = (t * 64 + lane) * 4;
+                    hh[u][t] = *reinterpret_cast<const ushort4*>(rowh + (o < a.d ? o : 0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const float cv = cvs[u];
+                float dot = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int o = (t * 64 + lane) * 4;
+                    if (o < a.d) {
+                        const ushort4 h = hh[u][t];
+                        rp_acc4(g[t], dot, cv, make_float4(cvt16<F16>(h.x), cvt16<F16>(h.y), cvt16<F16>(h.z), cvt16<F16>(h.w)), wv[t]);
+                    }
+                }
+                csum += cv;
+                if (dout) {
+                    dot = wave_sum(dot);
+                    if (lane == 0) dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p + u] = dot;
+                }
+            }
+            p += NU;
+        };
+        while (p + RP_HU <= pend) batch(std::integral_constant<int, RP_HU>{});
+#if RP_HU > 2 && RP_TAIL2
+        if (p + 2 <= pend) batch(std::integral_constant<int, 2>{});      // (a remainder of two: together as well)
+#endif
+    }
+#endif
+    for (; p < pend; ++p) {
+        const float cv = cf[p];
+        const float* srow = src + (long)tk[p] * srs;
+        const uint16_t* srowh = srch + (long)tk[p] * srs;
+        float dot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = cb + (t * 64 + lane) * W;
+            if (o < a.d) {
+                if constexpr (VEC) {
+                    float4 s;
+                    if (a.src_bf16) {
+                        const ushort4 h = *reinterpret_cast<const ushort4*>(srowh + o);
+                        s = make_float4(cvt16<F16>(h.x), cvt16<F16>(h.y), cvt16<F16>(h.z), cvt16<F16>(h.w));
+                    } else s = *reinterpret_cast<const float4*>(srow + o);
+                    rp_acc4(g[t], dot, cv, s, wv[t]);
+                } else { const float s = a.src_bf16 ? cvt16<F16>(srowh[o]) : srow[o]; g[t][0] += cv * s; dot += s * wv[t][0]; }
+            }
+        }
+        csum += cv;
+        if (dout) {
+            dot = wave_sum(dot);
+            if (CW > 1) {                                   // every wave of the block walks the same entry list
+                const int par = (int)((p - p0) & 1u);
+                if (lane == 0) shdot[par][wave] = dot;
+                __syncthreads();
+                dot = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CW; ++c) dot += shdot[par][c];
+            }
+            if (lane == 0 && wave == (CW == 1 ? wave : 0))
+                dout[(long)(a.dot_slot_base < 0 ? layer - col / a.F : a.dot_slot_base) * dstride + p] = dot;
+        }
+    }
+}
+
+// What follows the entry lists for a row whose gradient sums (g) and coefficient sum are complete: the dense contribution
+// of the compacted aux pass, the dec_norms term, then the materialised gradient or the Adam update (+ shadow, + squared length).
+template <int NT, bool VEC, int CW, bool F16, bool SQ>
+__device__ __forceinline__ void row_pass_finish(const RowPassArgs& a, const int r, const int col, const int lane, const int wave, const int cb,
+                                                float (&wv)[NT][VEC ? 4 : 1], float (&g)[NT][VEC ? 4 : 1], float (&mm)[NT][VEC ? 4 : 1],
+                                                float (&vv)[NT][VEC ? 4 : 1], float csum) {
+    constexpr int W = VEC ? 4 : 1;
+    const long ro = (long)r * a.d;
+    if (a.extra) {
+        const int mr = a.extra_map[col];
+        if (mr >= 0) {
+            const float* er = a.extra + (long)mr * a.d;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int o = cb + (t * 64 + lane) * W;
+                if (o < a.d) {
+                    if (VEC) { const float4 x = *reinterpret_cast<const float4*>(er + o); g[t][0] += x.x; g[t][1 % W] += x.y; g[t][2 % W] += x.z; g[t][3 % W] += x.w; }
+                    else g[t][0] += er[o];
+                }
+            }
+            if (a.extra_colsum) csum += a.extra_colsum[mr];
+        }
+    }
+    if (a.colsum_out && lane == 0 && (CW == 1 || wave == 0)) a.colsum_out[col] = csum;
+    if (a.row_dnorm) {
+        const float cf = a.row_dnorm[col] / sqrtf(a.row_sq[col]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int c = 0; c < W; ++c) g[t][c] += cf * wv[t][c];
+    }
+    if (a.grad_out) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = cb + (t * 64 + lane) * W;
+            if (o < a.d) {
+                if (VEC) *reinterpret_cast<float4*>(a.grad_out + ro + o) = make_float4(g[t][0], g[t][1 % W], g[t][2 % W], g[t][3 % W]);
+                else a.grad_out[ro + o] = g[t][0];
+            }
+        }
+        return;
+    }
+    // loss scaling (clt_set_loss_scaling): the gathered sources carry the loss scale, the gradient is unscaled here; a step
+    // whose gradients overflowed leaves weights, moments and shadow untouched (the dots and column sums above are still
+    // written: the later passes of this step run, and skip likewise)
+    bool skip = false;
+    if constexpr (SQ) skip = clt_skip_update();     // (the row's length is still written: of the unchanged row)
+    else if (clt_skip_update()) return;
+    const float unscale = clt_dev_state.grad_unscale;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int o = cb + (t * 64 + lane) * W;
+        if (o >= a.d || skip) continue;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            float gg = g[t][c] * unscale, pp = wv[t][c];
+            if (a.wd != 0.0f) { if (a.adamw) pp *= (1.0f - a.lr * a.wd); else gg += a.wd * pp; }
+            // (explicit fused multiply-adds: left to the compiler, the contraction of these lines differed between the
+            // instantiations of this body — 1 ulp in v and W between kernels that must agree bit for bit)
+            mm[t][c] = __fmaf_rn(gg - mm[t][c], a.omb1, mm[t][c]);
+            vv[t][c] = __fmaf_rn(vv[t][c], a.b2, (a.omb2 * gg) * gg);
+            pp = __fmaf_rn(-a.step_size, mm[t][c] / __fmaf_rn(sqrtf(vv[t][c]), a.isb2, a.eps), pp);
+            wv[t][c] = pp;
+        }
+        if (VEC) {
+            rp_st4(a.W + ro + o, wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]);
+            rp_st4(a.m + ro + o, mm[t][0], mm[t][1 % W], mm[t][2 % W], mm[t][3 % W]);
+            rp_st4(a.v + ro + o, vv[t][0], vv[t][1 % W], vv[t][2 % W], vv[t][3 % W]);
+            if (a.shadow) rp_st2(a.shadow + ro + o, pack16<F16>(wv[t][0], wv[t][1 % W]), pack16<F16>(wv[t][2 % W], wv[t][3 % W]));
+        } else {
+            a.W[ro + o] = wv[t][0]; a.m[ro + o] = mm[t][0]; a.v[ro + o] = vv[t][0];
+            if (a.shadow) a.shadow[ro + o] = (uint16_t)pack16<F16>(wv[t][0], 0.0f);
+        }
+    }
+    if constexpr (SQ && CW == 1) if (a.sq_out) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (t * 64 + lane) * W;
+            if (o < a.d) s = VEC ? s + sq4(wv[t][0], wv[t][1 % W], wv[t][2 % W], wv[t][3 % W]) : __fmaf_rn(wv[t][0], wv[t][0], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) a.sq_out[r] = s;
+    }
+}
+
+// the row's weights (when anything needs them) and, for the Adam form, its moments: issued together, the moments are in
+// flight during the entry loop (used only after it)
+template <int NT, bool VEC>
+__device__ __forceinline__ void row_pass_load(const RowPassArgs& a, const long ro, const int lane, const int cb, float (&wv)[NT][VEC ? 4 : 1],
+                                              float (&g)[NT][VEC ? 4 : 1], float (&mm)[NT][VEC ? 4 : 1], float (&vv)[NT][VEC ? 4 : 1],
+                                              const bool moments) {
+    constexpr int W = VEC ? 4 : 1;
+    const bool need_w = a.dot_out != nullptr || a.dot_out2 != nullptr || a.grad_out == nullptr || a.row_dnorm != nullptr;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int o = cb + (t * 64 + lane) * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) { g[t][c] = 0.0f; wv[t][c] = 0.0f; mm[t][c] = 0.0f; vv[t][c] = 0.0f; }
+        if (need_w && o < a.d) {
+            if (VEC) { const float4 x = rp_ld4(a.W + ro + o); wv[t][0] = x.x; wv[t][1 % W] = x.y; wv[t][2 % W] = x.z; wv[t][3 % W] = x.w; }
+            else wv[t][0] = a.W[ro + o];
+        }
+    }
+    if (moments && !a.grad_out) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = cb + (t * 64 + lane) * W;
+            if (o < a.d) {
+                if (VEC) {
+                    const float4 x = rp_ld4(a.m + ro + o); mm[t][0] = x.x; mm[t][1 % W] = x.y; mm[t][2 % W] = x.z; mm[t][3 % W] = x.w;
+                    const float4 y = rp_ld4(a.v + ro + o); vv[t][0] = y.x; vv[t][1 % W] = y.y; vv[t][2 % W] = y.z; vv[t][3 % W] = y.w;
+                } else { mm[t][0] = a.m[ro + o]; vv[t][0] = a.v[ro + o]; }
+            }
+        }
+    }
+}
+
+// The streaming pass itself, one wave per row (or CW waves per long row).  It is written as ONE body on purpose: the same steps
+// factored into the row_pass_load / _walk / _finish helpers above (which row_pass_hot_kernel is made of) compile to 144 instead of
+// 110 registers per lane here, i.e. three instead of four waves per SIMD for the kernel that is 70 % of the headline step.
+// SQ: also write the updated row's squared length (a.sq_out) — its own instantiation: compiled into the common kernel the
+// few extra instructions cost the headline launch 20 us (830 -> 851, register allocation of the whole body moved)
 template <int NT, bool VEC, int CW, bool F16, bool SQ = false>
 __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r) {
     constexpr int W = VEC ? 4 : 1;
@@ -196,6 +416,7 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
     const int lane = threadIdx.x & 63;
     const int cb = CW == 1 ? 0 : wave * NT * 64 * W;          // first element of this wave's chunk
     const int col = a.col0 + r;
+    if (CW == 1 && a.hot_min_len > 0 && a.col_start[col + 1] - a.col_start[col] > (uint32_t)a.hot_min_len) return;   // row_pass_hot_kernel's
     const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
     const long srs = (long)a.L * a.d;
     const long ro = (long)r * a.d;
@@ -409,6 +630,7 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
 // pointers, source and layer.  On a feature shard the per-matrix launches are 35..180 us long and spend a fifth of that
 // ramping up and draining.
 constexpr int RP_GROUP_MAX = 16;
+constexpr int HOT_GRID = 512;                             // blocks of row_pass_hot_kernel (each walks the hot list with this stride)
 struct RowPassGroup {
     int n; int row_end[RP_GROUP_MAX];                     // cumulative row counts
     float* W[RP_GROUP_MAX]; float* m[RP_GROUP_MAX]; float* v[RP_GROUP_MAX]; uint16_t* shadow[RP_GROUP_MAX];
@@ -427,13 +649,89 @@ __global__ __launch_bounds__(TPB) void row_pass_group_kernel(RowPassArgs a, RowP
     row_pass_body<NT, true, 1, F16>(a, r);
 }
 
-// dval[p] = sum_{s < nslots(p)} dots[s*stride + p], nslots = L - layer(column of p) (cross-layer) or 1
-__global__ void reduce_dots_kernel(const float* __restrict__ dots, long stride, const uint32_t* __restrict__ col_start, int ncols,
-                                   int F, int L, int cross_layer, float* __restrict__ dval) {
+
+// ---- heavy-tailed feature frequencies ------------------------------------------------------------------------------
+// A feature that fires in 10 % of the tokens is a 400-entry list, which one wave of row_pass_kernel would walk alone
+// while the rows around it finish in a few entries.  Columns longer than `hot_min_len` are therefore listed once per step
+// (hot_columns_kernel) and their rows go through row_pass_hot_kernel: one block of HW waves per row, wave w walks the
+// w-th contiguous segment of the list (dots are per entry and written directly; the gradient sums of the segments are
+// combined through LDS in wave order: a fixed summation order, as everywhere), wave 0 finishes the row (Adam).
+__global__ void hot_columns_kernel(const uint32_t* __restrict__ col_start, int ncols, uint32_t min_len, int32_t* __restrict__ hot_list,
+                                   uint32_t hot_cap, uint32_t* __restrict__ hot_count) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
-    const int ns = cross_layer ? L - c / F : 1;
-    for (uint32_t p = col_start[c]; p < col_start[c + 1]; ++p) {
+    if (col_start[c + 1] - col_start[c] > min_len) {
+        const uint32_t pos = atomicAdd(hot_count, 1u);
+        if (pos < hot_cap) hot_list[pos] = c;      // (hot_cap >= entries / (min_len + 1) + 1 by the caller: never exceeded)
+    }
+}
+
+template <int NT> struct HotWaves { static constexpr int value = NT <= 3 ? 16 : 8; };   // (LDS: HW * NT KB for the partial sums)
+template <int NT, bool F16>
+__global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_hot_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
+                                                                               const int32_t* __restrict__ hot_list,
+                                                                               const uint32_t* __restrict__ hot_count, uint32_t hot_cap) {
+    constexpr int HW = HotWaves<NT>::value;
+    __shared__ float part[HW][NT * 256];
+    __shared__ float pcs[HW];
+    __shared__ float shdot[2][1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (use_group) {
+        const int i = blockIdx.y;
+        a.W = grp.W[i]; a.m = grp.m[i]; a.v = grp.v[i]; a.shadow = grp.shadow[i]; a.src = grp.src[i]; a.src_layer = grp.src_layer[i];
+        a.rows = grp.row_end[i] - (i ? grp.row_end[i - 1] : 0);
+    }
+    const uint32_t nh = min(*hot_count, hot_cap);
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const int col = hot_list[h];
+        const int r = col - a.col0;
+        if (r < 0 || r >= a.rows) continue;                        // (block-uniform)
+        const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
+        float wv[NT][4], g[NT][4], mm[NT][4], vv[NT][4];
+        row_pass_load<NT, true>(a, (long)r * a.d, lane, 0, wv, g, mm, vv, wave == 0);
+        float csum = 0.0f;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t* cs = pass ? a.col_start2 : a.col_start;
+            if (!cs) continue;
+            const uint32_t p0 = cs[col], p1 = cs[col + 1];
+            const uint32_t per = (p1 - p0 + HW - 1) / HW;
+            const uint32_t q0 = min(p1, p0 + (uint32_t)wave * per), q1 = min(p1, q0 + per);
+            row_pass_walk<NT, true, 1, F16>(a, pass, col, layer, lane, wave, 0, q0, q1, p0, wv, g, csum, shdot);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<float4*>(&part[wave][(t * 64 + lane) * 4]) = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
+        if (lane == 0) pcs[wave] = csum;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll 1
+            for (int w = 1; w < HW; ++w) {                         // wave order: the row's fixed summation order
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 x = *reinterpret_cast<const float4*>(&part[w][(t * 64 + lane) * 4]);
+                    g[t][0] += x.x; g[t][1] += x.y; g[t][2] += x.z; g[t][3] += x.w;
+                }
+                csum += pcs[w];
+            }
+            row_pass_finish<NT, true, 1, F16, true>(a, r, col, lane, 0, 0, wv, g, mm, vv, csum);
+        }
+        __syncthreads();
+    }
+}
+
+// dval[p] = sum_{s < nslots(p)} dots[s*stride + p], nslots = L - layer(column of p) (cross-layer) or 1.  One thread per ENTRY
+// (a thread per column serialises a hot column's thousands of entries); the entry's layer from the layers' first CSC positions.
+__global__ void reduce_dots_kernel(const float* __restrict__ dots, long stride, const uint32_t* __restrict__ col_start, int ncols,
+                                   int F, int L, int cross_layer, float* __restrict__ dval) {
+    const uint32_t n = col_start[ncols];
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        int ns = 1;
+        if (cross_layer) {
+            int layer = 0;
+            while (layer + 1 < L && col_start[(long)(layer + 1) * F] <= p) ++layer;
+            ns = L - layer;
+        }
         float s = 0.0f;
         for (int k = 0; k < ns; ++k) s += dots[(long)k * stride + p];
         dval[p] = s;
@@ -621,8 +919,10 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double lr,
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
                             const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
-                            const float* row_sq, float* sq_out, void* stp) {
+                            const float* row_sq, float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap,
+                            int hot_min_len, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
+    if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
     if (sq_out && (grad_out || d > 1024)) return CLT_ERR_SHAPE;   // the updated row's norm: Adam form, one wave per row
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
@@ -645,6 +945,8 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     hipStream_t st = as_stream(stp);
     const int chunks = (d + (vec ? 256 : 64) - 1) / (vec ? 256 : 64);   // 64-lane iterations a whole row needs
     const dim3 g4((rows + 3) / 4), g1(rows);
+    const bool hot = hot_list && vec && chunks <= 4;          // (one wave per row with 16-byte lanes: the hot-row form applies)
+    a.hot_min_len = hot ? hot_min_len : 0;
 #define RP(NT_, VEC_, CW_, GRID_)                                                                                          \
     do {                                                                                                                    \
         if (CW_ == 1 && sq_out) {                                                                                           \
@@ -671,6 +973,25 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
         else return CLT_ERR_RANGE;
     }
 #undef RP
+    if (hot) {
+        RowPassGroup none = {};
+#define RPH(NT_)                                                                                                          \
+    do {                                                                                                                    \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap); \
+    } while (0)
+        if (chunks <= 1) RPH(1); else if (chunks <= 2) RPH(2); else if (chunks <= 3) RPH(3); else RPH(4);
+#undef RPH
+    }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap, uint32_t* hot_count,
+                           void* stp) {
+    if (!col_start || ncols <= 0 || min_len < 1 || !hot_list || !hot_count || hot_cap == 0) return CLT_ERR_SHAPE;
+    if (hipMemsetAsync(hot_count, 0, sizeof(uint32_t), as_stream(stp)) != hipSuccess) return CLT_ERR_LAUNCH;
+    hipLaunchKernelGGL(hot_columns_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), col_start, ncols, (uint32_t)min_len,
+                       hot_list, hot_cap, hot_count);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
@@ -678,7 +999,9 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
                                    const int* rows, const int* src_layer, const void* const* src, int d, int F, int L,
                                    const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
                                    double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
-                                   int src_bf16, void* stp) {
+                                   int src_bf16, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
+                                   void* stp) {
+    if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if (nmat <= 0 || d <= 0 || F <= 0 || L <= 0 || step < 1 || !W || !m || !v || !rows || !src_layer || !src) return CLT_ERR_SHAPE;
     if (nmat > RP_GROUP_MAX) return 1;
     const int chunks = (d + 255) / 256;
@@ -704,6 +1027,7 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
     a.wd = (float)weight_decay; a.step_size = (float)(lr / bc1); a.isb2 = (float)(1.0 / sqrt(bc2)); a.adamw = adamw;
     hipStream_t st = as_stream(stp);
     const dim3 grid((unsigned)((total + 3) / 4));
+    a.hot_min_len = hot_list ? hot_min_len : 0;
 #define RPG(NT_)                                                                                             \
     do {                                                                                                      \
         if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_group_kernel<NT_, true>), grid, dim3(TPB), 0, st, a, g); \
@@ -711,6 +1035,15 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
     } while (0)
     if (chunks <= 1) RPG(1); else if (chunks <= 2) RPG(2); else if (chunks <= 3) RPG(3); else RPG(4);
 #undef RPG
+    if (hot_list) {                                        // the hot rows of every matrix of the group: grid.y = matrix
+#define RPGH(NT_)                                                                                              \
+    do {                                                                                                        \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap); \
+    } while (0)
+        if (chunks <= 1) RPGH(1); else if (chunks <= 2) RPGH(2); else if (chunks <= 3) RPGH(3); else RPGH(4);
+#undef RPGH
+    }
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
@@ -718,7 +1051,7 @@ int clt_sparse_reduce_dots_f32(const float* dots, long stride, const uint32_t* c
                                float* dval, void* stp) {
     if (L <= 0 || F <= 0) return CLT_ERR_SHAPE;
     const int ncols = L * F;
-    hipLaunchKernelGGL(reduce_dots_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), dots, stride, col_start,
+    hipLaunchKernelGGL(reduce_dots_kernel, dim3(2048), dim3(TPB), 0, as_stream(stp), dots, stride, col_start,
                        ncols, F, L, cross_layer, dval);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }

@@ -365,6 +365,7 @@ class _Decoder:
         layer l's gradient slab [B, d] once it can be computed; the matrices are then walked from the last layer down."""
         dev = S.csc_val.device
         slots = self.L if self.clt else 1
+        ops.hot_columns(S)                      # (listed once, on this stream, before passes are dealt to other streams)
         dots = torch.empty(slots, S.cap, dtype=torch.float32, device=dev)
         dots2 = torch.empty(slots, S2.cap, dtype=torch.float32, device=dev) if S2 is not None else None
         if self.bf16 and slabs is None:    # bf16 mode: gathered g rows as bf16 (fp32 accumulate), half the gather bytes
@@ -404,6 +405,11 @@ class _Decoder:
         else:
             begun = None
         two = ROW_PASS_STREAMS > 1 and small and ops.TIMING is None and len(todo) > 1
+        if two and fused is not None and begun is None:
+            # the optimizer creates (zero-fills) a matrix's moment buffers in begin_fused on its first step: all of them on this
+            # stream BEFORE the side stream's wait point below — created inside the loop, a side-stream pass raced its own
+            # matrix's zero fill (first step only; found by the heavy-tail test of round 3)
+            begun = {l: fused.begin_fused(w) for l, (_, w) in todo}
         if two:
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             ev = torch.cuda.Event()

@@ -407,7 +407,14 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  * (row_dnorm[col] / sqrt(row_sq[col])) * W[r,:], the gradient through dec_norms (clt_lightning.py:438-448).
  * sq_out (optional, [rows]; Adam form and d <= 1024 only, CLT_ERR_SHAPE otherwise): sq_out[r] = |W[r,:]|^2 of the
  * UPDATED row, bit-identical to clt_row_sqnorm_f32 on the updated matrix — the next step's dec_norms
- * (clt_lightning.py:440-444) without another read of the weights. */
+ * (clt_lightning.py:440-444) without another read of the weights.
+ * hot_list / hot_count / hot_cap / hot_min_len (optional; from clt_sparse_hot_columns on the SAME col_start with the same
+ * min_len): rows whose list holds more than hot_min_len entries are processed by a second launch with a block of 16 waves
+ * per row (each wave a contiguous segment of the list, the segments' sums combined in wave order) instead of one wave —
+ * real dictionaries are heavy-tailed: a feature active in 10 % of the tokens is a 400-entry list.  Applies to d <= 1024
+ * with 16-byte-aligned operands (ignored otherwise: one wave, or CW waves per long row, as before). */
+int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap,
+                           uint32_t* hot_count, void* stream);
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
@@ -415,7 +422,8 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             long dot_stride2, int dot_slot, float* colsum_out, double lr, double beta1, double beta2, double eps,
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
                             const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
-                            float* sq_out, void* stream);
+                            float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
+                            void* stream);
 /* Several weight matrices of one decoder in ONE launch of the same pass (Adam in place; no gradient output, second list,
  * compact contribution or row term): matrix i has rows[i] rows of d floats (row r <-> CSC column r), gathers from src[i]
  * (a [B][L][d] tensor, layer src_layer[i]; fp32, or 16-bit when src_bf16) and writes its dots to slot
@@ -426,7 +434,8 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
                                   const int* rows, const int* src_layer, const void* const* src, int d, int F, int L,
                                   const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
                                   double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
-                                  int src_bf16, void* stream);
+                                  int src_bf16, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
+                                  void* stream);
 
 /* Column compaction for the TopK-aux pass (clt_lightning.py:539-553: top k_aux among the DEAD features, second decoder
  * pass): the dead columns are gathered so that the pass runs as a dense sub-problem of n_pad columns per layer.

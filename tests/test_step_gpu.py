@@ -554,3 +554,81 @@ def test_debug_yaml_config_end_to_end(tmp_path, golden):
         assert_close(got, cur["losses"], 5e-4, 1e-7, f"100-step curve (fused={fused})")
         for k, p in mod.model.named_parameters():
             assert_close(p, cur["final_params"][k], 1e-3, 0.05, f"final {k}")
+
+
+@pytest.mark.parametrize("prec", ["32", "bf16-mixed"])
+@pytest.mark.parametrize("kind", ["batchtopk", "topk-aux-lists"])
+def test_heavy_tailed_feature_frequencies_hot_rows(kind, prec, monkeypatch):
+    """Real dictionaries are heavy-tailed: here a few features of every layer fire in about half of the tokens (encoder-bias
+    offsets), so their lists hold hundreds of entries where the median column holds a handful.  Those rows go through the
+    multi-wave launch of the weight pass (ops.HOT_MIN_LEN: segments of a list per wave, combined in wave order) and the
+    per-entry dot reduction; loss, every gradient and the first fused Adam step against the oracle — and the same step with
+    the hot-row form switched off (one wave per row) agrees to summation-order rounding."""
+    from crosslayer_transcoder_amd import engine, ops, precision
+    from oracle import clt_oracle as O
+    from tests.build_cases import build_module
+    B, L, d, F, k = 768, 3, 128, 512, 8
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, L, d, generator=g)
+    y = 0.5 * x * torch.randn(L, d, generator=g) + 0.1 * torch.randn(B, L, d, generator=g)
+    batch = torch.stack([x, y], 1)
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.randn(L, d, generator=g) * 0.01}
+    params["encoder.b"][:, 5::97] = 0.9              # ~6 features per layer far above the selection threshold half of the time
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    aux = kind != "batchtopk"
+    nl = {"kind": "topk", "k": k} if aux else {"kind": "batchtopk", "k": k, "e": 0.1}
+    loss = {"kind": "topk", "topk_aux": {"kind": "topk", "k": 24}, "tokens_till_dead": 100, "aux_loss_scale": 1 / 32} if aux else {"kind": "base"}
+    la0 = torch.zeros(L, F, dtype=torch.long)
+    if aux:
+        la0[:, ::4] = 5000
+        params["encoder.b"][:, ::4] = -1.5
+        params["encoder.b"][:, 8::100] = -0.25       # dead features that dominate the aux selection: hot columns of the SECOND list
+        la0[:, 8::100] = 5000
+        monkeypatch.setattr(engine, "COMPACT_AUX", False)     # the aux pass on activation lists (second list of the row pass)
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": nl, "loss": loss}, "opt": {"lr": 1e-3},
+            "batches": batch[None], "init_params": params, "last_active0": la0, "max_steps": 10}
+    bf16 = prec != "32"
+    outs = {}
+    hot0 = ops.HOT_MIN_LEN
+    assert hot0 > 0
+    for hot in (hot0, 0):
+        monkeypatch.setattr(ops, "HOT_MIN_LEN", hot)
+        mod = build_module(case)
+        mod.log_metrics_every = 0
+        with precision(prec):
+            outs[hot] = mod.compute_step(batch.cuda(), 0)
+    out = outs[hot0]
+    S = out["lists"]
+    lens = (S.col_start[1:] - S.col_start[:-1]).long()
+    assert int(lens.max()) > 200 and int((lens > hot0).sum()) >= 10 and float(lens.float().median()) < 20, "the case must be heavy-tailed"
+    buf = {"last_active": la0.clone(), "threshold": torch.zeros(1)}
+    import contextlib
+    with (O.operand_rounding(torch.bfloat16) if bf16 else contextlib.nullcontext()):
+        ref = O.training_step(batch, params, O.standardizer_init(batch), case["cfg"], buf)
+    assert_close(out["loss"], ref["loss"], 1e-3 if bf16 else 2e-5, 1e-7, "loss")
+    if not bf16:
+        assert torch.equal(out["features"].cpu() > 0, ref["features"] > 0)
+    for k_, gref in ref["grads"].items():
+        got = out["grads"][k_].reshape(gref.shape).cpu()
+        if bf16:
+            rel = float((got - gref).norm() / (gref.norm() + 1e-12))
+            assert rel < 2e-2, f"{kind} {prec} grad {k_}: rel l2 {rel:.3g}"
+        else:
+            assert_close(got, gref, 1e-4, 4e-6 * float(gref.abs().max()) + 1e-12, f"{kind} grad {k_}")
+        other = outs[0]["grads"][k_].reshape(gref.shape).cpu()
+        assert_close(got, other, 1e-4, 4e-6 * float(gref.abs().max()) + 1e-12, f"{kind} {prec} grad {k_}: hot-row form vs one wave per row")
+    # Adam fused into the (hot-row) passes: first-step moments against the materialised gradients of the same regime
+    monkeypatch.setattr(ops, "HOT_MIN_LEN", hot0)
+    mod2 = build_module(case)
+    mod2.log_metrics_every = 0
+    opt, _ = mod2.attach_optimizers()
+    with precision(prec):
+        mod2.fused_train_step(batch.cuda(), 0, opt)
+    for k_, p in mod2.model.named_parameters():
+        gfull = out["grads"][k_].reshape(p.shape).double()
+        m = opt.state[p]["exp_avg"].double()
+        rel = float((m - 0.1 * gfull).norm() / (0.1 * gfull.norm() + 1e-30))
+        assert rel < (1e-2 if bf16 else 1e-4), f"{kind} {prec} fused exp_avg {k_}: rel l2 {rel:.3g}"
+        assert float((p.detach().double() - params[k_].double().to(p.device)).abs().max()) <= 1.01e-3
