@@ -83,6 +83,7 @@ SIGNATURES = {
     "clt_operand_format": (I, []),
     "clt_gemm_bf16_nt_out16": (I, [P, P, P, I, I, I, L, L, L, I, L, L, L, P, L, P]),
     "clt_gemm_bf16_nt_kseg_out16": (I, [P, P, P, I, I, I, I, L, L, L, P]),
+    "clt_gemm_nt_variant": (I, [I, I]),
     "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,

@@ -73,7 +73,16 @@ struct SelEpi {
 };
 
 // F16: fp16 operands (clt_set_loss_scaling) instead of bf16 — the same kernel around v_mfma_f32_16x16x32_f16
-template <int EPI, bool F16 = false>
+// SPEC (round 3, the store epilogues): wave roles.  vmcnt retires in order, so a wave that has just issued its C stores cannot
+// learn that a LATER operand DMA piece has landed without waiting for those stores.  With SPEC the waves 0-3 ("loaders")
+// issue ALL operand DMA pieces and never store; the waves 4-7 ("storers") issue ALL C stores — their own accumulators' and,
+// handed over through the LDS transposition slabs, their partner wave's — and never wait on vmcnt in the main loop.  All
+// eight waves run the same MFMA loop.  Measured (profiles/r03_gemm_ab.md): +3..7 % where the main loop is long (K 2048 ..
+// 8192: no wave's DMA wait sits behind a store any more, and the loaders' 16 pieces per k-tile are in flight longer), -2..3 %
+// on the K = 768 encoder shapes, whose cost is the store traffic itself (the storers issue twice the stores while the loaders
+// idle at the slab barriers).  The host picks the form by K.  (The loaders' piece offsets: one per-lane offset per operand,
+// the pieces' row stride in the scalar offset; per-piece clamped offsets only on edge tiles — sixteen per-lane offsets spill.)
+template <int EPI, bool F16 = false, bool SPEC = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
@@ -93,7 +102,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     const int wm = w >> 2, wn = w & 3;                  // wave position: 2 along B rows (128 each), 4 along A rows (64 each)
     const int nwg = tilesA * tilesB;
     const int fr = lane & 15, fq = lane >> 4;
-
     // ---- virtual block -> (batch, tile) with an XCD-aware, bijective remap -----------------------------
     // The grid is persistent (one block per CU, a multiple of 8): block p walks the virtual blocks p, p + G, ...,
     // so vb & 7 is the block's XCD for every tile it processes.
@@ -129,6 +137,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     int vB[4], vA[4];
     __amdgpu_buffer_rsrc_t rB, rA;
     long brow0 = 0;
+    const bool loader = !SPEC || w < 4;
+    bool edge = false;                                  // SPEC: the tile touches the matrix edge (rows clamped piece by piece)
+    int eb0 = 0, ea0 = 0;
     // (extent 2 GiB: per-lane offsets stay below it, and an offset with bit 31 set reads as zero — the k tail below)
     auto rsrc = [](const uint16_t* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p), 0, (int)0x80000000u, 0x00020000); };
     // K need only be a multiple of 8: in the last k-tile the lanes whose 16-byte chunk starts at k >= K aim out of the
@@ -137,6 +148,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     const int my_chunk = (lane & 7) ^ ((w * 4 + (lane >> 4)) & 7);
     const int tail_oob = (K % TK != 0 && my_chunk * 8 >= K % TK) ? (int)0x80000000u : 0;
     auto aim = [&](const Tile& t) {
+        if constexpr (SPEC) {
+            // piece i of loader w covers rows (i * 4 + w) * 8 .. + 7 of both operand tiles: vB[0] / vA[0] hold piece 0's
+            // per-lane offset, piece i adds i * 32 rows in the scalar offset
+            const int row = w * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            vB[0] = (int)(((long)row * ldb + chunk * 8) * 2);
+            vA[0] = (int)(((long)row * lda + chunk * 8) * 2);
+            vB[1] = chunk * 16;                             // (edge tiles: the chunk's byte offset alone)
+            edge = t.a0 + TA > M || t.b0 + TB > N;
+            eb0 = t.b0; ea0 = t.a0;
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 8 + w) * 8 + (lane >> 3);
@@ -157,6 +179,31 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         const int oob = kt == nk - 1 ? tail_oob : 0;
         __amdgpu_buffer_rsrc_t rb = rB;
         if (EPI != 1 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
+        if constexpr (SPEC) {
+            if (!loader) return;
+            const int koa = kt * (TK * 2);
+            if (!edge) {
+                const int sbs = (int)(ldb * 64), sas = (int)(lda * 64);     // 32 rows, in bytes
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 4 + w) * 1024), 16, vB[0] | oob, sob + i * sbs, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 4 + w) * 1024), 16, vA[0] | oob, koa + i * sas, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int r = eb0 + (i * 4 + w) * 8 + (lane >> 3); r = (r < N ? r : N - 1) - eb0;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 4 + w) * 1024), 16, (r * (int)ldb * 2 + vB[1]) | oob, sob, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int r = ea0 + (i * 4 + w) * 8 + (lane >> 3); r = (r < M ? r : M - 1) - ea0;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)(base + OP_BYTES + (i * 4 + w) * 1024), 16, (r * (int)lda * 2 + vB[1]) | oob, koa, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
@@ -201,7 +248,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         // first k-tile (staged before the previous tile's epilogue).  Vector-memory operations retire in issue order, so
         // after an interior tile's store epilogue (exactly 32 stores per lane, no loads) the prefetch is complete once all
         // but the 32 youngest operations are: the stores keep draining under the main loop
-        if (stores_after_prefetch) { if (EPI == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+        if (SPEC) { if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }     // (loaders hold no stores; storers wait for nothing)
+        else if (stores_after_prefetch) { if (EPI == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (bare s_barrier: __syncthreads() carries a release fence, i.e. a compiler-inserted vmcnt(0) that would wait for the
         // stores just issued; what the barriers of this kernel order is LDS traffic, waited for explicitly)
@@ -236,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                         fb[r & 7] = ldB(base, r >> 3, r & 7);
                     } else if (!LAST) {
                         if (r == 16) {
-                            if (diag & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (ablation: no wait for the DMA — wrong results)
+                            if ((diag & 4) || !loader) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (storers hold no DMA piece; ablation 4: no wait for the DMA — wrong results)
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                             if (kt + 2 < nk) stage(kt & 1, kt + 2);
 #pragma unroll
@@ -336,6 +384,80 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             for (uint32_t i = tid; i < staged; i += 512) {
                 const uint32_t pos = gbase + i;
                 if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
+            }
+        } else if (SPEC && EPI == 2) {
+            // ---- 16-bit store epilogue, loader / storer waves: every wave transposes its accumulators through its LDS slab,
+            // the storers push their partner's slab and their own out (2 x 4 stores per lane and pass)
+            uint16_t* C = reinterpret_cast<uint16_t*>(C0) + (long)batch * sC;
+            unsigned char* ebuf = nt_smem + EPI_BASE_STORE + w * (16 * EROW);
+            const int er = lane >> 4, ec = (lane & 15) * 8;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    *reinterpret_cast<f32x4*>(ebuf + fr * EROW + (m * 16 + fq * 4) * 4) = acc[m][n];
+                LDS_BARRIER();
+                if (!loader) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {        // half 0: the partner loader's slab (B rows 0..127), 1: this wave's own
+                        const unsigned char* sbuf = ebuf - (1 - half) * 4 * (16 * EROW);
+                        const int col = b0 + half * 128 + ec;
+                        f32x4 b0v = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, b1v = b0v;
+                        if (bias) { b0v = *reinterpret_cast<const f32x4*>(bias + half * 128 + ec); b1v = *reinterpret_cast<const f32x4*>(bias + half * 128 + ec + 4); }
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int lr = it * 4 + er;
+                            const int row = a0 + wn * 64 + n * 16 + lr;
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sbuf + lr * EROW + ec * 4) + b0v;
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(sbuf + lr * EROW + ec * 4 + 16) + b1v;
+                            if (row < M && col < N) {
+                                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                                typedef __attribute__((address_space(1))) u32x4 gvec;
+                                u32x4 o;
+                                o[0] = pack16t<F16>(v0[0], v0[1], bad16); o[1] = pack16t<F16>(v0[2], v0[3], bad16);
+                                o[2] = pack16t<F16>(v1[0], v1[1], bad16); o[3] = pack16t<F16>(v1[2], v1[3], bad16);
+                                __builtin_nontemporal_store(o, (gvec*)(C + (long)row * ldc + col));
+                            }
+                        }
+                    }
+                }
+                if (n < 3) LDS_BARRIER();                     // (after the last pass: the next tile's first barrier)
+            }
+        } else if (SPEC && EPI == 0) {
+            // ---- fp32 store epilogue, loader / storer waves (2 x 8 stores per storer lane and pass)
+            float* C = grp ? grp[batch].c : C0 + (long)batch * sC;
+            unsigned char* ebuf = nt_smem + EPI_BASE_STORE + w * (16 * EROW);
+            const int er = lane >> 5, ec = (lane & 31) * 4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    *reinterpret_cast<f32x4*>(ebuf + fr * EROW + (m * 16 + fq * 4) * 4) = acc[m][n];
+                LDS_BARRIER();
+                if (!loader) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const unsigned char* sbuf = ebuf - (1 - half) * 4 * (16 * EROW);
+                        const int col = b0 + half * 128 + ec;
+                        f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + half * 128 + ec);
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int lr = it * 2 + er;
+                            const int row = a0 + wn * 64 + n * 16 + lr;
+                            f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + lr * EROW + ec * 4);
+                            if (row < M && col < N) {
+                                typedef __attribute__((address_space(1))) f32x4 gvec;
+                                gvec* dst = (gvec*)(C + (long)row * ldc + col);
+                                if (racc) v = round16v<F16>(v, bad16);
+                                v += bv;
+                                if (accumulate) { const f32x4 old = *dst; v += old; }
+                                __builtin_nontemporal_store(v, dst);
+                            }
+                        }
+                    }
+                }
+                if (n < 3) LDS_BARRIER();
             }
         } else if (EPI == 2) {
             // ---- bf16 store epilogue: C leaves as bf16 (half the bytes AND half the store instructions of the fp32 form:
@@ -447,7 +569,20 @@ int persistent_grid(long nblk) {
     }
     return (int)(nblk < cus ? nblk : cus);
 }
+// which form of the kernel the store epilogues launch: 1 = every wave loads and stores (rounds 1-2), 2 = loader / storer
+// waves, 0 = by shape: the loader / storer form for 2048 <= K <= 8192 (measured, profiles/r03_gemm_ab.md: 8192^3 1372 ->
+// 1464 TFLOP/s, 4096^3 1283 -> 1319, the K = 4096 weight gradient 1194 -> 1234; the K = 768 encoder shapes 840 -> 819 and
+// the K = 32768 decoder forward 960 -> 933 are better off with every wave doing both)
+int g_nt_variant = 0;
 }  // namespace
+
+// test / A-B hook: see include/clt_hip.h
+extern "C" int clt_gemm_nt_variant(int variant, int reserved) {
+    const int old = g_nt_variant;
+    if (variant >= 0 && variant <= 2) g_nt_variant = variant;
+    (void)reserved;
+    return old;
+}
 
 // (the fp16 store / rounding epilogues raise the loss scaler's overflow flag: this unit needs the state too)
 CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_gemm_nt)
@@ -467,38 +602,26 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
     const long nblk = (long)tilesA * tilesB * batch;
     if (nblk > 0x7fffffffL) return 1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-    if (clt_host_state.fp16 && out16) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
-                           lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(), SelEpi{}, Bseg, kts,
-                           (const GemmGroup*)nullptr);
-        CLT_LAUNCH_CHECK();
-        return CLT_OK;
-    }
-    if (clt_host_state.fp16) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<0, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
-                           lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
-                           gemm_diag(), SelEpi{}, Bseg, kts, grp);
-        CLT_LAUNCH_CHECK();
-        return CLT_OK;
-    }
+    const unsigned grid = (unsigned)persistent_grid(nblk);
+    const int diag = gemm_diag();
+#define NT_GO(EPI_, F16_, SPEC_)                                                                                              \
+    do {                                                                                                                        \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<EPI_, F16_, SPEC_>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;    \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_, F16_, SPEC_>), dim3(grid), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, ldc, \
+                           sA, sB, sC, bias, sBias, EPI_ == 2 ? 0 : accumulate, tilesA, tilesB, (int)nblk, diag, SelEpi{}, Bseg, kts,       \
+                           EPI_ == 2 ? (const GemmGroup*)nullptr : grp);                                                        \
+    } while (0)
+    const bool spec = g_nt_variant == 2 || (g_nt_variant == 0 && K >= 2048 && K <= 8192);
+    const bool f16 = clt_host_state.fp16 != 0;
     if (out16) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
-        hipLaunchKernelGGL(gemm_nt_bf16_kernel<2>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
-                           lda, ldb, ldc, sA, sB, sC, bias, sBias, 0, tilesA, tilesB, (int)nblk, gemm_diag(), SelEpi{}, Bseg, kts,
-                           (const GemmGroup*)nullptr);
-        CLT_LAUNCH_CHECK();
-        return CLT_OK;
+        if (f16) { if (spec) NT_GO(2, true, true); else NT_GO(2, true, false); }
+        else { if (spec) NT_GO(2, false, true); else NT_GO(2, false, false); }
+    } else {
+        if (f16) { if (spec) NT_GO(0, true, true); else NT_GO(0, true, false); }
+        else { if (spec) NT_GO(0, false, true); else NT_GO(0, false, false); }
     }
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<0>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, st, A, B, C, M, N, K,
-                       lda, ldb, ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk,
-                       gemm_diag(), SelEpi{}, Bseg, kts, grp);
+#undef NT_GO
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -340,6 +340,12 @@ int clt_gemm_bf16_nt_out16(const uint16_t* A, const uint16_t* B, uint16_t* C, in
                            int batch, long sA, long sB, long sC, const float* bias, long sBias, void* stream);
 int clt_gemm_bf16_nt_kseg_out16(const uint16_t* A, const uint16_t* const* Bseg, uint16_t* C, int M, int N, int nseg, int kseg,
                                 long lda, long ldb, long ldc, void* stream);
+/* Test / A-B hook (no counterpart in the reference): which form of the NT kernel the store-epilogue entry points launch —
+ * 1: every wave issues operand DMA pieces and C stores (rounds 1-2); 2: waves 0-3 issue all operand DMA pieces, waves 4-7 all C
+ * stores (their partner's accumulators handed over through LDS), so no wave waits for a store before it can see an operand
+ * piece land; 0 (default): by shape, form 2 for 2048 <= K <= 8192 (profiles/r03_gemm_ab.md).  `reserved` is ignored.  Results
+ * are bit-identical between the forms (same k order per element).  Returns the previous form. */
+int clt_gemm_nt_variant(int variant, int reserved);
 /* Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
  * groups: DEVICE array of records {int64 aoff (elements into A); const uint16_t* B; float* C}.  Used for the dense
  * cross-layer decoder forward (clt.py:334-343): all (target layer, source layer) pairs — 78 at L = 12 — fill the chip
