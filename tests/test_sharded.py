@@ -67,3 +67,32 @@ def test_bench_starts_its_own_ranks():
     assert line["rccl_ranks"] == (2 if have2 else 0)
     assert ("REHEARSAL" in line["config"]["parallelism"]) == (not have2)
     assert line["value"] > 0 and line["config"]["regime"] == "activation lists"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [
+    ("headline batchtopk", []),
+    ("config 4: CLT JumpReLU + pre-activation loss", ["--nonlinearity", "jumprelu"]),
+    ("config 4 in fp16 with loss scaling", ["--nonlinearity", "jumprelu", "--precision", "16-mixed"]),
+    ("config 5: CLT TopK + aux loss", ["--nonlinearity", "topk", "--aux"]),
+])
+def test_bench_eight_rank_rehearsal_of_the_sharded_regimes(name, extra):
+    """`bench.py --gpus 8 --rehearsal` at toy size for the regimes the driver's 8-GPU run can meet (BASELINE.json configs 3, 4
+    and 5): eight ranks share this box's GPU(s) and exchange over gloo, so every sharded branch of the step (list exchange,
+    JumpReLU losses, aux selection, fp16 flag agreement) runs with world_size 8 before a real node does.  A schedule smoke:
+    the line must say REHEARSAL and carry a finite loss."""
+    import json
+    import math
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("a real 8-GPU node runs the RCCL path itself")
+    small = ["--features", "2048", "--batch", "256", "--layers", "3", "--d-acts", "128", "--k", "8", "--steps", "2", "--warmup", "2",
+             "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearsal"] + small + extra, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, name + "\n" + p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and "REHEARSAL" in line["config"]["parallelism"] and line["rccl_ranks"] == 0
+    assert line["value"] > 0 and math.isfinite(line["config"]["loss"])
