@@ -86,6 +86,10 @@ SIGNATURES = {
     "clt_gemm_nt_variant": (I, [I, I]),
     "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, I, P]),
+    "clt_select_rows_ext_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "clt_select_rows_ext_info": (SZ, [I, I, I, I, I, I, I, I]),
+    "clt_select_rows_ext_f32": (I, [I, I, P, I, I, I, I, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "clt_gemm_bf16_select_rows": (I, [P, P, I, I, I, L, L, I, L, L, P, L, P, P, P, P, I, I, P]),
     "clt_select_lists_ext_f32": (I, [I, I, I, I, I, I, P, F32, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P,
                                      P, P, SZ, P]),
     "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, I, I, P]),
@@ -103,7 +107,7 @@ SIGNATURES = {
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CltError(RuntimeError):

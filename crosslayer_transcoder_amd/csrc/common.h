@@ -131,6 +131,11 @@ int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,
                            const uint8_t* col_mask, int L, uint32_t* row_cnt, uint32_t* col_cnt, hipStream_t st,
                            void* ws = nullptr, size_t wsb = 0);
+int clt_internal_topk_merge_slots(const uint32_t* slot_key, const int32_t* slot_idx, const uint32_t* slot_cnt, int slots, int k, int F,
+                                  int L, long rows, int32_t* idx_out, float* val_out, uint32_t* row_cnt, uint32_t* col_cnt,
+                                  const int32_t* gate, hipStream_t st);
+size_t clt_internal_row_bounds_workspace_bytes(long rows, int F, int j);
+int clt_internal_row_bounds(const float* x, long rows, int F, int j, float* lb, void* ws, size_t wsb, hipStream_t st);
 // scratch the list-output form of long rows wants (two streaming passes, select.hip); 0: that form does not apply
 size_t clt_internal_topk_rows_workspace_bytes(long rows, int F, int k);
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,

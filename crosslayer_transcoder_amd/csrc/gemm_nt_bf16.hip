@@ -70,7 +70,12 @@ struct SelEpi {
     const uint32_t* ctl;          // SelCtl records of 4 words: [lb key, candidate count, -, -]
     uint32_t* cand_key; uint32_t* cand_idx; uint32_t capS;
     int seg_per_batch;            // 1: segment = batch index (per-layer selection); 0: one segment
+    // Epilogue 3 ("row select", per-row TopK): the lower bound is PER ROW of C (row_lb[row * nbatch + batch], a float) and a
+    // candidate goes into its row's slot block: slot_key / slot_idx [rows][slots] (idx = the column), position by a global
+    // atomic on slot_cnt[row]; rows = M * nbatch, row index = row * nbatch + batch (the [B][L] order of the pre-activations)
+    const float* row_lb; uint32_t* slot_cnt; int slots, nbatch;
 };
+constexpr bool is_select(int epi) { return epi == 1 || epi == 3; }
 
 // F16: fp16 operands (clt_set_loss_scaling) instead of bf16 — the same kernel around v_mfma_f32_16x16x32_f16
 // SPEC (round 3, the store epilogues): wave roles.  vmcnt retires in order, so a wave that has just issued its C stores cannot
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             vA[i] = (int)(((long)ra * lda + chunk * 8) * 2);
         }
         brow0 = (long)t.b0 * ldb;
-        rA = rsrc(A0 + ((EPI != 1 && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
-        rB = rsrc(((EPI != 1 && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
+        rA = rsrc(A0 + ((!is_select(EPI) && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
+        rB = rsrc(((!is_select(EPI) && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
     };
     typedef __attribute__((address_space(3))) void lds_void;
     auto stage = [&](int buf, int kt) {
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         int sob = kt * (TK * 2);
         const int oob = kt == nk - 1 ? tail_oob : 0;
         __amdgpu_buffer_rsrc_t rb = rB;
-        if (EPI != 1 && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
+        if (!is_select(EPI) && Bseg) { const int sg = kt / kts; rb = rsrc(Bseg[sg] + brow0); sob = (kt - sg * kts) * (TK * 2); }
         if constexpr (SPEC) {
             if (!loader) return;
             const int koa = kt * (TK * 2);
@@ -317,16 +322,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         slot ^= 1;
         uint32_t bad16 = 0;                              // fp16 mode: some conversion of this tile's epilogue overflowed
 
-        if (EPI == 1) {
-            // ---- select epilogue: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
+        if (is_select(EPI)) {
+            // ---- select epilogues: block-level staging in LDS (slot allocation by LDS atomics), one global atomic per block
+            // (1: one lower bound per segment) or one per candidate on its row's slot counter (3: per-row lower bounds)
+            constexpr bool ROWS = EPI == 3;
             uint32_t* skey = reinterpret_cast<uint32_t*>(nt_smem + EPI_BASE_SELECT);
             uint32_t* sidx = skey + ESTG;
             uint32_t* scnt = sidx + ESTG;                     // [0] staged count, [1] global base
-            const int seg = se.seg_per_batch ? batch : 0;
-            uint32_t* gcnt = const_cast<uint32_t*>(se.ctl) + 4 * seg + 1;
-            const uint32_t lb = se.ctl[4 * seg];
-            uint32_t* ck = se.cand_key + (size_t)seg * se.capS;
-            uint32_t* ci = se.cand_idx + (size_t)seg * se.capS;
+            const int seg = (!ROWS && se.seg_per_batch) ? batch : 0;
+            uint32_t* gcnt = ROWS ? nullptr : const_cast<uint32_t*>(se.ctl) + 4 * seg + 1;
+            const uint32_t lb = ROWS ? 0u : se.ctl[4 * seg];
+            uint32_t* ck = ROWS ? se.cand_key : se.cand_key + (size_t)seg * se.capS;
+            uint32_t* ci = ROWS ? se.cand_idx : se.cand_idx + (size_t)seg * se.capS;
+            // rows form: a candidate's place = its row's slot block (row index = flat index / N)
+            auto to_slot = [&](uint32_t key, uint32_t fi) {
+                const uint32_t r = fi / (uint32_t)N, f = fi - r * (uint32_t)N;
+                const uint32_t pos = atomicAdd(&se.slot_cnt[r], 1u);
+                if (pos < (uint32_t)se.slots) { ck[(size_t)r * se.slots + pos] = key; ci[(size_t)r * se.slots + pos] = f; }
+            };
             if (tid == 0) scnt[0] = 0;
             LDS_BARRIER();
             float lbf = key_f32(lb);                          // fast reject in float: !(v < lbf) also lets NaNs through
@@ -342,9 +355,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             }
             // (B-fragment index outermost: one bias vector live at a time — the accumulators leave few registers)
             uint32_t flat_row[4];
+            float rlb[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                flat_row[n] = (uint32_t)((long)batch * sC + (long)(a0 + wn * 64 + n * 16 + fr) * ldc);
+            for (int n = 0; n < 4; ++n) {
+                const int row = a0 + wn * 64 + n * 16 + fr;
+                flat_row[n] = (uint32_t)((long)batch * sC + (long)row * ldc);
+                rlb[n] = ROWS ? (row < M ? se.row_lb[(long)row * se.nbatch + batch] : INFINITY) : lbf;
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int col = b0 + wm * 128 + m * 16 + fq * 4;
@@ -355,19 +372,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
                     f32x4 v = acc[m][n];
                     if (racc) v = round16v<F16>(v, bad16);
                     v += bv;
+                    const float lbn = ROWS ? rlb[n] : lbf;
                     const bool in = row < M && col < N;
-                    const bool maybe = in && (!(v[0] < lbf) || !(v[1] < lbf) || !(v[2] < lbf) || !(v[3] < lbf));
-                    if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate
+                    const bool maybe = in && (!(v[0] < lbn) || !(v[1] < lbn) || !(v[2] < lbn) || !(v[3] < lbn));
+                    if (__ballot(maybe) == 0ull) continue;      // ~70 % of the 64 x 4 groups hold no candidate (one bound per segment)
                     // rare (about 0.1 % of the elements): each lane appends its own candidates, one LDS atomic apiece
                     if (maybe) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const uint32_t key = f32_key(v[c]);
-                            if (key >= lb) {
+                            if (ROWS ? !(v[c] < lbn) : key >= lb) {
                                 const uint32_t fi = flat_row[n] + (uint32_t)(col + c);
                                 const uint32_t off = atomicAdd(&scnt[0], 1u);
                                 if (off < (uint32_t)ESTG) { skey[off] = key; sidx[off] = fi; }
-                                else {                           // staging full (pathological tile): straight to the global list
+                                else if (ROWS) to_slot(key, fi);   // staging full (pathological tile): straight to the global lists
+                                else {
                                     const uint32_t pos = atomicAdd(gcnt, 1u);
                                     if (pos < se.capS) { ck[pos] = key; ci[pos] = fi; }
                                 }
@@ -378,12 +397,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             }
             LDS_BARRIER();
             const uint32_t staged = min(scnt[0], (uint32_t)ESTG);
-            if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
-            LDS_BARRIER();
-            const uint32_t gbase = scnt[1];
-            for (uint32_t i = tid; i < staged; i += 512) {
-                const uint32_t pos = gbase + i;
-                if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
+            if (ROWS) {
+                for (uint32_t i = tid; i < staged; i += 512) to_slot(skey[i], sidx[i]);
+            } else {
+                if (tid == 0 && staged) scnt[1] = atomicAdd(gcnt, staged);
+                LDS_BARRIER();
+                const uint32_t gbase = scnt[1];
+                for (uint32_t i = tid; i < staged; i += 512) {
+                    const uint32_t pos = gbase + i;
+                    if (pos < se.capS) { ck[pos] = skey[i]; ci[pos] = sidx[i]; }
+                }
             }
         } else if (SPEC && EPI == 2) {
             // ---- 16-bit store epilogue, loader / storer waves: every wave transposes its accumulators through its LDS slab,
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         }
         if (F16) clt_raise_inf_flag(bad16);
         if (!more) break;
-        stores_after_prefetch = EPI != 1 && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
+        stores_after_prefetch = !is_select(EPI) && !accumulate && !(diag & 1) && a0 + TA <= M && b0 + TB <= N;
         vb = nvb;
     }
 }
@@ -680,7 +703,7 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
                                 LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, true>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
                            (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, flags & CLT_GEMM_ROUND_ACC, tilesA, tilesB, (int)nblk, gemm_diag(),
-                           SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0, (const GemmGroup*)nullptr);
+                           SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch, nullptr, nullptr, 0, 0}, (const uint16_t* const*)nullptr, 0, (const GemmGroup*)nullptr);
         CLT_LAUNCH_CHECK();
         return CLT_OK;
     }
@@ -689,8 +712,38 @@ extern "C" int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M,
     hipLaunchKernelGGL(gemm_nt_bf16_kernel<1>, dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B,
                        (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, flags & CLT_GEMM_ROUND_ACC, tilesA, tilesB, (int)nblk,
                        gemm_diag(),
-                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch}, (const uint16_t* const*)nullptr, 0,
+                       SelEpi{ctl, cand_key, cand_idx, capS, seg_per_batch, nullptr, nullptr, 0, 0}, (const uint16_t* const*)nullptr, 0,
                        (const GemmGroup*)nullptr);
+    CLT_LAUNCH_CHECK();
+    return CLT_OK;
+}
+
+// Per-row form: C is never written; element (batch, row, col) is a candidate when it is >= row_lb[row * batch_count + batch]
+// and goes into the slot block of row index row * batch_count + batch.  Requires sC == N and ldc == batch * N (the [B][L][F]
+// layout: flat index / N = the row index).  Returns 1 when the shape does not qualify for the fast kernel.
+extern "C" int clt_gemm_bf16_select_rows(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, int batch,
+                                         long sA, long sB, const float* bias, long sBias, const float* row_lb, uint32_t* slot_cnt,
+                                         uint32_t* slot_key, uint32_t* slot_idx, int slots, int flags, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !row_lb || !slot_cnt || !slot_key || !slot_idx || slots <= 0) return CLT_ERR_SHAPE;
+    const bool ok = K % 8 == 0 && N % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 && sBias % 4 == 0 &&
+                    aligned16(A) && aligned16(B) && (!bias || aligned16(bias)) && dma_offsets_fit(lda, ldb, K);
+    if (!ok) return 1;
+    const long ldc = (long)batch * N, sC = N;
+    if ((unsigned long long)M * batch * N > 0xffffffffull) return CLT_ERR_RANGE;
+    const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
+    const long nblk = (long)tilesA * tilesB * batch;
+    if (nblk > 0x7fffffffL) return 1;
+    const SelEpi se{nullptr, slot_key, slot_idx, 0u, 0, row_lb, slot_cnt, slots, batch};
+#define NT_ROWS(F16_)                                                                                                           \
+    do {                                                                                                                        \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<3, F16_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;                                                \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<3, F16_>), dim3((unsigned)persistent_grid(nblk)), dim3(512), LDS_BYTES, as_stream(stream), A, B, \
+                           (float*)nullptr, M, N, K, lda, ldb, ldc, sA, sB, sC, bias, sBias, flags & CLT_GEMM_ROUND_ACC, tilesA, tilesB, (int)nblk, \
+                           gemm_diag(), se, (const uint16_t* const*)nullptr, 0, (const GemmGroup*)nullptr);                     \
+    } while (0)
+    if (clt_host_state.fp16) NT_ROWS(true); else NT_ROWS(false);
+#undef NT_ROWS
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }

@@ -805,19 +805,27 @@ template <int NQ>                                      // slots per lane: chunks
 __global__ __launch_bounds__(256) void topk_merge_kernel(const uint32_t* __restrict__ ckey, const int32_t* __restrict__ cidx, int n, int k,
                                                          int F, int L, long nrows, int32_t* __restrict__ idx_out,
                                                          float* __restrict__ val_out, uint32_t* __restrict__ row_cnt,
-                                                         uint32_t* __restrict__ col_cnt) {
+                                                         uint32_t* __restrict__ col_cnt, const uint32_t* __restrict__ slot_cnt = nullptr,
+                                                         const int32_t* __restrict__ gate = nullptr) {
+    // slot_cnt (the fused encoder + per-row selection): only the first min(slot_cnt[row], n) slots of a row are filled, in
+    // arrival order (the rest of the block is stale); gate != 0: the attempt is void, every row stays empty
     __shared__ int32_t sidx[4][64];
     __shared__ uint32_t skey[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wv;
     if (row >= nrows) return;
+    if (gate && *gate) {
+        if (row_cnt && lane == 0) row_cnt[row] = 0;
+        return;
+    }
+    const int nr = slot_cnt ? (int)min(slot_cnt[row], (uint32_t)n) : n;
     uint32_t kq[NQ];
     int iq[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int p = q * 64 + lane;
-        kq[q] = p < n ? ckey[row * n + p] : 0u;
-        iq[q] = p < n ? cidx[row * n + p] : 0x7fffffff;
+        kq[q] = p < nr ? ckey[row * n + p] : 0u;
+        iq[q] = p < nr ? cidx[row * n + p] : 0x7fffffff;
     }
     uint32_t T = 0;                                       // exact k-th largest slot key (0: fewer than k slots are filled)
 #pragma unroll 1
@@ -945,6 +953,56 @@ int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, 
     } else
         hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TPB), 0, st, x, feat, F, k, idx_out, val_out, col_mask, L, row_cnt,
                            col_cnt);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+// Lower bound of every row's j-th largest value (the fused encoder + per-row selection's sample pass, select_lists.hip): the
+// chunk pass alone — a chunk's j largest positive values; the bound of a row = the largest, over its chunks, of a chunk's j-th
+// largest (that chunk alone holds j values >= it; one chunk: the row's exact j-th largest).  A row none of whose chunks holds j
+// positive values gets the smallest positive float: all its positive elements become candidates.
+__global__ void chunk_bound_kernel(const uint32_t* __restrict__ okey, long rows, int chunks, int j, float* __restrict__ lb) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    uint32_t best = 1u;                                   // (bit pattern of the smallest positive float)
+    for (int c = 0; c < chunks; ++c) {
+        const uint32_t* k = okey + (r * chunks + c) * j;
+        uint32_t m = 0xffffffffu;
+        for (int e = 0; e < j; ++e) m = min(m, k[e]);     // (unfilled places hold key 0)
+        if (m > 0x80000000u) best = max(best, m & 0x7fffffffu);      // key of a positive value = its bits | sign bit
+    }
+    lb[r] = __uint_as_float(best);
+}
+
+size_t clt_internal_row_bounds_workspace_bytes(long rows, int F, int j) {
+    if (j < 1 || j > 64 || F % 4) return 0;
+    const long chunks = (F + CHK - 1) / CHK;
+    return (size_t)rows * chunks * j * 8;
+}
+// returns 1 when the streaming form does not apply (the caller then takes the general per-row selection)
+int clt_internal_row_bounds(const float* x, long rows, int F, int j, float* lb, void* ws, size_t wsb, hipStream_t st) {
+    const size_t need = clt_internal_row_bounds_workspace_bytes(rows, F, j);
+    if (!need || !ws || wsb < need || !aligned16(x)) return 1;
+    const int chunks = (F + CHK - 1) / CHK;
+    const long waves = rows * chunks;
+    if ((waves + 3) / 4 > 0x7fffffffL) return 1;
+    uint32_t* ck = (uint32_t*)ws;
+    int32_t* ci = (int32_t*)(ck + (size_t)waves * j);
+    hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, F, j, (const uint8_t*)nullptr, 1, rows, chunks, ck, ci);
+    hipLaunchKernelGGL(chunk_bound_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const uint32_t*)ck, rows, chunks, j, lb);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+// Exact per-row top k (ties: lowest index) among each row's slot block — the second half of the streaming rows selection on its
+// own, for candidates that the encoder GEMM's row-select epilogue collected (select_lists.hip: clt_select_rows_ext_*).
+int clt_internal_topk_merge_slots(const uint32_t* slot_key, const int32_t* slot_idx, const uint32_t* slot_cnt, int slots, int k, int F,
+                                  int L, long rows, int32_t* idx_out, float* val_out, uint32_t* row_cnt, uint32_t* col_cnt,
+                                  const int32_t* gate, hipStream_t st) {
+    if (slots < 1 || slots > 1024 || k < 1 || k > 64 || rows <= 0) return CLT_ERR_RANGE;
+    const dim3 mg((unsigned)((rows + 3) / 4));
+#define TKM(NQ_) hipLaunchKernelGGL((topk_merge_kernel<NQ_>), mg, dim3(256), 0, st, slot_key, slot_idx, slots, k, F, L, rows, idx_out, val_out, \
+                                    row_cnt, col_cnt, slot_cnt, gate)
+    if (slots <= 256) TKM(4); else if (slots <= 512) TKM(8); else TKM(16);
+#undef TKM
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 

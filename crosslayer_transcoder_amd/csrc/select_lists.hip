@@ -645,6 +645,147 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
+
+// ---- rows mode fused with the encoder GEMM (clt_select_rows_ext_*) ---------------------------------------------------------
+// PerLayerTopK (topk.py:53-63) without the pre-activation tensor.  A row's lower bound comes from a SAMPLE of its own
+// pre-activations: the encoder GEMM on every `stride`-th feature ([rows][Fs] values, 1/16 of the work), whose j-th largest value
+// per row is >= at most ~j * stride of the row's F values and — being one of them — leaves at least j candidates.  It fails to
+// be a lower bound of the row's k-th value only when j of the sampled features are among the row's k - 1 largest:
+// C(k-1, j) / stride^j per row (k 16, stride 16, j 10: 3e-9; 1e-4 per step of 49152 rows).  The full-width GEMM's row-select
+// epilogue (gemm_nt_bf16.hip, epilogue 3) then files every element >= its row's bound in the row's slot block; the merge
+// kernel of the streaming rows selection takes the exact k largest of a block (ties: lowest index) and the lists are built as in
+// rows mode.  A row with fewer than k candidates under a positive bound, or more candidates than slots, raises the gate: the
+// caller reads it once and reruns the step with the unfused GEMM + selection.
+struct RPlan {
+    int rows, ncols;
+    size_t off_rowcnt, off_colcnt, off_colcur, off_slotcnt, zero_end, off_long, off_lb, off_sidx, off_sval, off_bidx, off_bval,
+           off_bcnt, off_bws, off_skey, off_sslot, total;
+};
+RPlan rplan(int B, int L, int F, int k, int slots, int Fs, int j) {
+    RPlan p;
+    p.rows = B * L; p.ncols = L * F;
+    size_t o = sizeof(Head);
+    auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+    p.off_rowcnt = take((size_t)p.rows * 4);
+    p.off_colcnt = take((size_t)p.ncols * 4);
+    p.off_colcur = take((size_t)p.ncols * 4);
+    p.off_slotcnt = take((size_t)p.rows * 4);
+    p.zero_end = o;
+    p.off_long = take((size_t)(p.rows > p.ncols ? p.rows : p.ncols) * 4);
+    p.off_lb = take((size_t)p.rows * 4);
+    p.off_sidx = take((size_t)p.rows * k * 4);
+    p.off_sval = take((size_t)p.rows * k * 4);
+    p.off_bidx = take((size_t)p.rows * j * 4);
+    p.off_bval = take((size_t)p.rows * j * 4);
+    p.off_bcnt = take((size_t)p.rows * 4);
+    {
+        const size_t a = clt_internal_topk_rows_workspace_bytes(p.rows, Fs, j), b = clt_internal_row_bounds_workspace_bytes(p.rows, Fs, j);
+        p.off_bws = take(a > b ? a : b);
+    }
+    p.off_skey = take((size_t)p.rows * slots * 4);
+    p.off_sslot = take((size_t)p.rows * slots * 4);
+    p.total = o;
+    return p;
+}
+bool rows_ext_ok(int B, int L, int F, int k, int slots, int Fs, int j) {
+    return B > 0 && L > 0 && F > 0 && k >= 1 && k <= 64 && k <= F && slots >= k && slots <= 1024 && Fs >= 1 && Fs <= F && j >= 1 && j <= 64 &&
+           j <= Fs && (unsigned long long)B * L * F < 0xffffffffull && (unsigned long long)L * F < 0x7fffffffull;
+}
+
+// bound of a row = the j-th largest sampled value when all j are positive, else the smallest positive float (every positive
+// element is a candidate, and nothing else is ever emitted: the bound cannot fail)
+constexpr uint32_t LB_ALL_POSITIVE = 1u;
+__global__ void row_bound_kernel(const float* __restrict__ bval, const uint32_t* __restrict__ bcnt, int rows, int j, float* __restrict__ lb) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float m = __uint_as_float(LB_ALL_POSITIVE);
+    if (bcnt[r] >= (uint32_t)j) {
+        m = INFINITY;
+        for (int e = 0; e < j; ++e) m = fminf(m, bval[(long)r * j + e]);
+    }
+    lb[r] = m;
+}
+// a row's slot block must hold a superset of its k largest positive values
+__global__ void rows_check_kernel(const uint32_t* __restrict__ slot_cnt, const float* __restrict__ lb, int rows, int k, int slots,
+                                  Head* __restrict__ head) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t c = slot_cnt[r];
+    if (c > (uint32_t)slots || (c < (uint32_t)k && __float_as_uint(lb[r]) != LB_ALL_POSITIVE)) head->gate = 1;
+}
+}  // namespace
+
+extern "C" {
+size_t clt_select_rows_ext_workspace_bytes(int B, int L, int F, int k, int slots, int Fs, int j) {
+    return rows_ext_ok(B, L, F, k, slots, Fs, j) ? rplan(B, L, F, k, slots, Fs, j).total : 0;
+}
+// which: 0 row bounds (float [rows]), 1 slot counters, 2 slot keys, 3 slot indices
+size_t clt_select_rows_ext_info(int B, int L, int F, int k, int slots, int Fs, int j, int which) {
+    if (!rows_ext_ok(B, L, F, k, slots, Fs, j)) return 0;
+    const RPlan p = rplan(B, L, F, k, slots, Fs, j);
+    switch (which) { case 0: return p.off_lb; case 1: return p.off_slotcnt; case 2: return p.off_skey; case 3: return p.off_sslot; default: return 0; }
+}
+// stage 0: clear the counters, row bounds from the sampled pre-activations pre_s [B*L][Fs]  (then run clt_gemm_bf16_select_rows);
+// stage 1: check every row's slot block and PUBLISH used_fallback[0] (1: void attempt); stage 2: exact selection per row + lists
+// (nothing is emitted after a void attempt: all rows empty).  The host may read the flag while stage 2 runs.
+int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int B, int L, int F, int k, int slots, int Fs, int j,
+                            uint32_t cap, uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
+                            float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
+                            int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
+    if (!rows_ext_ok(B, L, F, k, slots, Fs, j) || stage_lo < 0 || stage_hi > 2 || stage_lo > stage_hi || cap == 0) return CLT_ERR_SHAPE;
+    const RPlan p = rplan(B, L, F, k, slots, Fs, j);
+    if (!ws || wsb < p.total) return CLT_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stp);
+    char* w8 = (char*)ws;
+    Head* head = (Head*)w8;
+    uint32_t* row_cnt = (uint32_t*)(w8 + p.off_rowcnt);
+    uint32_t* col_cnt = (uint32_t*)(w8 + p.off_colcnt);
+    uint32_t* col_cur = (uint32_t*)(w8 + p.off_colcur);
+    uint32_t* slot_cnt = (uint32_t*)(w8 + p.off_slotcnt);
+    int32_t* long_list = (int32_t*)(w8 + p.off_long);
+    float* lb = (float*)(w8 + p.off_lb);
+    int32_t* sidx = (int32_t*)(w8 + p.off_sidx);
+    float* sval = (float*)(w8 + p.off_sval);
+    const int rows = p.rows, ncols = p.ncols;
+    const int32_t* gate = &head->gate;
+    for (int stage = stage_lo; stage <= stage_hi; ++stage) {
+        if (stage == 0) {
+            if (!pre_s) return CLT_ERR_SHAPE;
+            if (hipMemsetAsync(overflow, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            if (used_fallback && hipMemsetAsync(used_fallback, 0, 4, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            if (hipMemsetAsync(ws, 0, p.zero_end, st) != hipSuccess) return CLT_ERR_LAUNCH;
+            uint32_t* bcnt = (uint32_t*)(w8 + p.off_bcnt);
+            int rc = clt_internal_row_bounds(pre_s, rows, Fs, j, lb, w8 + p.off_bws, p.off_skey - p.off_bws, st);
+            if (rc == CLT_OK) continue;                    // (the streaming form; else the general per-row selection below)
+            if (rc != 1) return rc;
+            rc = clt_internal_topk_rows(pre_s, nullptr, rows, Fs, j, (int32_t*)(w8 + p.off_bidx), (float*)(w8 + p.off_bval), nullptr, 1,
+                                                  bcnt, nullptr, st, w8 + p.off_bws, p.off_skey - p.off_bws);
+            if (rc != CLT_OK) return rc;
+            hipLaunchKernelGGL(row_bound_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)(w8 + p.off_bval), bcnt, rows, j, lb);
+        } else if (stage == 1) {
+            hipLaunchKernelGGL(rows_check_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, slot_cnt, lb, rows, k, slots, head);
+            if (used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, used_fallback);
+        } else {
+            const int rc = clt_internal_topk_merge_slots((const uint32_t*)(w8 + p.off_skey), (const int32_t*)(w8 + p.off_sslot), slot_cnt, slots, k,
+                                                         F, L, rows, sidx, sval, row_cnt, col_cnt, gate, st);
+            if (rc != CLT_OK) return rc;
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, sidx, sval, k, F, L, rows, row_start, cap, ent_col,
+                               ent_val, overflow);
+            launch_scan(col_cnt, ncols, col_start, nullptr, fired, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);
+            hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap, col_start,
+                               col_cur, csc_tok, csc_val, csc_ent, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val, csc_ent,
+                               long_list, &head->long_cols, (const int32_t*)nullptr, 0);
+            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
+                               &head->long_cols, (const int32_t*)nullptr, 0);
+        }
+    }
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+}  // extern "C"
+
+namespace {
 }  // namespace
 
 extern "C" {

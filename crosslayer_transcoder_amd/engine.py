@@ -93,6 +93,8 @@ SELECT_MARGIN = 0.9
 #: tighten that bound from the floor SELECT_MARGIN towards 0.98 as far as the observed step-to-step change of the k-th value
 #: allows (device-side peak-hold of |T_t / T_{t-1} - 1|, clt_select_lists_ext_f32's drift state): fewer candidates in the epilogue
 ADAPTIVE_SELECT_MARGIN = True
+#: PerLayerTopK: fuse the encoder GEMM with the per-row selection (row bounds from a 1/16 feature sample; bf16, base loss, one GPU)
+FUSE_ENCODER_ROWS = bool(ab_switch("fuse_encoder_rows", 1))
 #: queue the decoder's gather forward before the host reads the fused selection's outcome flag
 SPECULATIVE_FORWARD = True
 #: streams the decoder's weight passes alternate over when the matrices are small (CLT_AB=rowpass_streams=1: off, for A/B runs)
@@ -633,6 +635,30 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             STATS["select_fallbacks"] += 1
             if drift is not None:
                 drift[:nseg] = 0.1
+    rows_unfused = getattr(mod, "_rows_unfused_once", False)       # (the rerun after a void per-row attempt)
+    mod._rows_unfused_once = False
+    if (S is None and sparse and bf16 and kind in ("base", "topk") and isinstance(nl, PerLayerTopK) and shard is None and FUSE_ENCODER_ROWS
+            and not rows_unfused and ops.encoder_select_rows_applicable(Bn, L, d, F, nl.k)):
+        # per-row TopK without the pre-activation tensor: lower bound of every row from a narrow GEMM on a rotating 1/16 sample
+        # of the features, candidates filed per row by the full GEMM's epilogue, exact selection on those
+        def _spec_rows(S_):
+            D_ = _Decoder(dec, None, shadow=optimizer is not None)
+            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None
+
+        S = ops.encoder_select_rows_lists(xo, _encoder_operand(enc), enc.b, nl.k, offset=batch_idx,
+                                          speculate=_spec_rows if SPECULATIVE_FORWARD else None)
+        STATS["fused_select_steps"] += 1
+
+        def _settle_rows():
+            nonlocal pending
+            pending = None
+            if S.confirm():
+                return
+            STATS["select_fallbacks"] += 1
+            mod._rows_unfused_once = True                # some row's bound did not hold: this step again, unfused
+            raise _VoidAttempt()
+
+        pending = _settle_rows
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
     # 16-bit regime of the JumpReLU module: the pre-activations (and later the feature gradient) leave their GEMMs as bf16 —
@@ -682,6 +708,13 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     N = Bn * L * d
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"
+
+    def pre_acts():
+        """The pre-activations, computed now when the fused encoder + selection never wrote them (aux pass on a path that reads them)."""
+        nonlocal pre
+        if pre is None:
+            pre = ops.encoder_fwd(xo, _encoder_operand(enc), enc.b)
+        return pre
 
     lists_only = sparse and kind != "jumprelu"           # every gradient comes from the lists (TopK family; ReLU + base loss)
     # (not under fp16 loss scaling: a later group's gradient slab could overflow after an earlier group's weights were updated)
@@ -814,7 +847,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 if bf16 and F % 4 == 0 and d % 8 == 0 and Bn * n_pad >= 256 * 256 and COMPACT_AUX_GEMM_COLUMNS:
                     pre_c = ops.encoder_fwd_columns(xo, enc.Wt, enc.b, cidx)
                 else:
-                    pre_c = ops.gather_cols(pre, cidx, float("-inf"))
+                    pre_c = ops.gather_cols(pre_acts(), cidx, float("-inf"))
                 if shard is None:
                     feat_c = ops.topk_rows(pre_c, min(aux.k, n_pad))
                 else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
@@ -832,7 +865,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 fc16 = ops.jumprelu_fwd_bf16(feat_c, None)[:2] if (bf16 and COMPACT_AUX_FUSED_OPERANDS and Bn % 8 == 0) else None
                 aux_r = Dc.fwd(feat_c, feat_op=fc16[0] if fc16 is not None else None)
             else:
-                S2 = _select_lists(aux, pre, dead, shard)
+                S2 = _select_lists(aux, pre_acts(), dead, shard)
                 aux_r = D.sparse_fwd(S2)
             aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
             terms["aux"] = (aux_sum[0] / N).float()

@@ -1117,6 +1117,100 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     return s, T
 
 
+#: fused encoder + per-row TopK: every ROWS_SAMPLE_STRIDE-th feature is sampled; a row's bound is the j-th largest sampled
+#: value, j chosen so that the bound exceeds the row's k-th value with probability <= ROWS_FAIL_ODDS per row
+ROWS_SAMPLE_STRIDE, ROWS_FAIL_ODDS = 16, 3e-9
+
+
+ROWS_SLOTS = 1024
+
+
+def _rows_plan(k: int):
+    """(j, slots) of the fused per-row selection for k, or None when it does not apply.  The bound fails when j of the sampled
+    features are among the row's k - 1 largest: P[Binomial(k - 1, 1 / stride) >= j].  The number of a row's elements above the
+    j-th largest of its sample is about stride * Gamma(j): the slot block must hold that with the same odds
+    (P[Gamma(j) > slots / stride] = P[Poisson(slots / stride) < j])."""
+    import math
+    if not 1 <= k <= 64:
+        return None
+    p = 1.0 / ROWS_SAMPLE_STRIDE
+    n = k - 1
+    tail = lambda j: sum(math.comb(n, i) * p ** i * (1 - p) ** (n - i) for i in range(j, n + 1))  # noqa: E731
+    j = next((j for j in range(1, 65) if tail(j) <= ROWS_FAIL_ODDS), None)
+    if j is None:
+        return None
+    x = ROWS_SLOTS / ROWS_SAMPLE_STRIDE
+    overflow = sum(math.exp(-x) * x ** i / math.factorial(i) for i in range(j))
+    return (j, ROWS_SLOTS) if overflow <= ROWS_FAIL_ODDS else None
+
+
+def encoder_select_rows_applicable(Bn: int, L: int, d: int, F: int, k: int) -> bool:
+    plan = _rows_plan(k)
+    Fs = F // ROWS_SAMPLE_STRIDE
+    return (plan is not None and F % ROWS_SAMPLE_STRIDE == 0 and Fs % 4 == 0 and Fs >= 4 * plan[0] and d % 8 == 0 and F % 4 == 0
+            and Bn * L * F < 2 ** 32)
+
+
+def encoder_select_rows_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor], k: int, offset: int = 0,
+                              speculate=None) -> SparseLists:
+    """Encoder forward fused with the PerLayerTopK selection (topk.py:53-63): the pre-activation tensor is never written.
+    A first, narrow GEMM on the features offset, offset + stride, ... gives every (token, layer) row a lower bound of its k-th
+    largest value; the full GEMM's epilogue files the elements above their row's bound per row; the exact selection runs on
+    those.  Returns the lists at once with lists.confirm() -> bool pending (False: the attempt was void — some row's bound did
+    not hold or its slot block overflowed — the lists are then EMPTY and the caller reruns the unfused path).
+    speculate(lists): work that only reads the lists, queued before the host read (as in encoder_select_lists)."""
+    Bn, L, d = xs.shape
+    F = Wt.shape[1]
+    _chk(xs, op16()); _chk(Wt, op16())
+    stride = ROWS_SAMPLE_STRIDE
+    assert encoder_select_rows_applicable(Bn, L, d, F, k)
+    Fs = F // stride
+    j, slots = _rows_plan(k)
+    offset = int(offset) % stride
+    dev = xs.device
+    dims = (Bn, L, F, k, slots, Fs, j)
+    ws = workspace(lib.clt_select_rows_ext_workspace_bytes(*dims), dev)
+    off = [lib.clt_select_rows_ext_info(*dims, w) for w in range(4)]
+    base = ws.data_ptr()
+    s = _empty_lists(Bn, L, F, max(1, k * Bn * L), dev)
+    fb = torch.zeros(1, dtype=torch.int32, device=dev)
+    pre_s = torch.empty(Bn, L, Fs, dtype=torch.float32, device=dev)
+    bias_s = b[:, offset::stride].contiguous() if b is not None else None
+    _gemm("clt_gemm_bf16", xs, 0, Wt, offset * d, pre_s, 0, Bn, Fs, d, L * d, stride * d, L * Fs, False, True, batch=L, sA=d, sB=d * F,
+          sC=Fs, bias=bias_s, sBias=Fs, round_acc=AUTOCAST_PRE)
+
+    def stages(lo, hi):
+        call("clt_select_rows_ext_f32", lo, hi, pre_s.data_ptr(), *dims, s.cap, s.row_start.data_ptr(), s.ent_col.data_ptr(),
+             s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(), s.csc_val.data_ptr(), s.csc_ent.data_ptr(),
+             s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(), fb.data_ptr(), base, ws.numel(), _stream())
+
+    stages(0, 0)
+    rc = _timed_raw("gemm", 2.0 * Bn * F * d * L, "clt_gemm_bf16_select_rows", xs.data_ptr(), Wt.data_ptr(), Bn, F, d, L * d, d, L, d, d * F,
+                    b.data_ptr() if b is not None else None, F, base + off[0], base + off[1], base + off[2], base + off[3], slots,
+                    GEMM_ROUND_ACC if AUTOCAST_PRE else 0, _stream())
+    if rc != 0:
+        raise CltError("clt_gemm_bf16_select_rows", rc)
+    stages(1, 1)                         # outcome flag published: the host read below completes while stage 2 runs
+    ev = torch.cuda.Event()
+    ev.record()
+    stages(2, 2)
+    spec = speculate(s) if speculate is not None else None
+    side, host = _flag_reader(dev)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        host.copy_(fb, non_blocking=True)
+    s.used_fallback = fb
+    s.kth = None
+    s.speculated = spec
+
+    def confirm() -> bool:
+        side.synchronize()
+        return int(host) == 0
+
+    s.confirm = confirm
+    return s
+
+
 def new_select_drift(S: int, device) -> torch.Tensor:
     """Initial state of the adaptive candidate bound: no history (the bound starts at its floor and tightens over ~30 steps)."""
     return torch.zeros(2 * S, device=device)

@@ -375,6 +375,27 @@ int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, in
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                              float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                              int32_t* used_fallback, void* workspace, size_t ws_bytes, void* stream);
+/* PerLayerTopK fused with the encoder GEMM (topk.py:53-63 on clt.py:157-165's result, which is never written): per-row lower
+ * bounds from a sample of the row's own pre-activations, candidates filed per row by the GEMM epilogue, exact per-row
+ * selection (ties: lowest index) on the candidates, lists as clt_select_lists_f32(mode 0) builds them — bit-identical lists
+ * whenever the attempt holds.  One GPU, k <= 64, slots (candidate places per row) <= 1024.
+ *   1. the caller runs the encoder GEMM on every stride-th feature (clt_gemm_bf16 with ldb * stride) into pre_s [B*L][Fs];
+ *   2. clt_select_rows_ext_f32 stage 0: clears the counters; bound of a row = the j-th largest of its Fs sampled values when
+ *      all j are positive, else 0;
+ *   3. clt_gemm_bf16_select_rows: the full-width GEMM; element (layer l, token b, feature f) >= bound[b * L + l] goes into slot
+ *      block b * L + l (row_lb / slot_cnt / slot_key / slot_idx = workspace + clt_select_rows_ext_info(..., 0 / 1 / 2 / 3));
+ *   4. stage 1: used_fallback[0] = 1 when some row's block overflowed or holds fewer than k candidates under a positive bound
+ *      (the sample's j-th largest was above the row's k-th value: probability C(k-1, j) / stride^j per row) — the attempt is
+ *      void, stage 2 then emits empty lists and the caller reruns the unfused GEMM + selection; stage 2: selection + lists. */
+size_t clt_select_rows_ext_workspace_bytes(int B, int L, int F, int k, int slots, int Fs, int j);
+size_t clt_select_rows_ext_info(int B, int L, int F, int k, int slots, int Fs, int j, int which);
+int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int B, int L, int F, int k, int slots, int Fs, int j,
+                            uint32_t cap, uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
+                            float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
+                            int32_t* used_fallback, void* workspace, size_t ws_bytes, void* stream);
+int clt_gemm_bf16_select_rows(const uint16_t* A, const uint16_t* B, int M, int N, int K, long lda, long ldb, int batch, long sA,
+                              long sB, const float* bias, long sBias, const float* row_lb, uint32_t* slot_cnt, uint32_t* slot_key,
+                              uint32_t* slot_idx, int slots, int flags, void* stream);
 /* Feature-sharded per-row TopK (mode 0 under sharding; k <= 2048): local top-k rows, then the exact global k-th value
  * of every row by 8 rounds of 4-bit radix counts.  Stages stage_lo..stage_hi with host collectives in between:
  *   after stages 0..7: SUM over ranks of the uint32 array at exchange offset 0 (length info 1 = rows*16)

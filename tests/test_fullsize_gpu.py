@@ -119,3 +119,42 @@ def test_perlayer_topk_streaming_selection_full_size():
     assert torch.equal(S.ent_col[int(rs[7 * L + 3]):int(rs[7 * L + 3]) + k].cpu() - 3 * F, torch.arange(k, dtype=torch.int32))
     del dense
     torch.cuda.empty_cache()
+
+
+def test_perlayer_topk_fused_with_encoder_full_size():
+    """PerLayerTopK at the headline shape with the selection in the encoder GEMM's epilogue (49152 rows, bounds from a 1/16
+    feature sample, about 160 candidates a row): every list array equals the unfused path's (encoder GEMM, 6.4 GB of
+    pre-activations, streaming rows selection), for two sample offsets; the slot blocks stay far from their capacity."""
+    import crosslayer_transcoder_amd as cta
+    from crosslayer_transcoder_amd import ops
+    from crosslayer_transcoder_amd._lib import lib
+    B, L, d, F, k = 4096, 12, 768, 32768, 16
+    try:
+        cta.set_precision("bf16-mixed")
+        ops.sync_operand_format()
+        g = torch.Generator(device="cuda:0").manual_seed(6)
+        xs = torch.randn(B, L, d, device="cuda:0", generator=g).bfloat16()
+        Wt = ((torch.rand(L, F, d, device="cuda:0", generator=g) * 2 - 1) * F ** -0.5).bfloat16()
+        b = torch.randn(L, F, device="cuda:0", generator=g) * 0.02
+        want = ops.select_lists(ops.encoder_fwd(xs, Wt, b), k, ops.SELECT_ROWS)
+        torch.cuda.empty_cache()
+        j, slots = ops._rows_plan(k)
+        dims = (B, L, F, k, slots, F // ops.ROWS_SAMPLE_STRIDE, j)
+        for offset in (0, 7):
+            got = ops.encoder_select_rows_lists(xs, Wt, b, k, offset=offset)
+            assert got.confirm()
+            n = int(want.total)
+            assert n == int(got.total) == k * B * L
+            for name in ("row_start", "col_start", "fired"):
+                assert torch.equal(getattr(got, name), getattr(want, name)), name
+            for name in ("ent_col", "ent_val", "csc_tok", "csc_val", "csc_ent"):
+                assert torch.equal(getattr(got, name)[:n], getattr(want, name)[:n]), name
+            ws = ops.workspace(lib.clt_select_rows_ext_workspace_bytes(*dims), xs.device)
+            o = lib.clt_select_rows_ext_info(*dims, 1)
+            cnt = ws[o:o + 4 * B * L].view(torch.int32)
+            print(f"[fused rows, offset {offset}] candidates per row: mean {float(cnt.float().mean()):.1f}, max {int(cnt.max())} of {slots} slots")
+            assert int(cnt.max()) <= slots // 2
+    finally:
+        cta.set_precision("32")
+        ops.sync_operand_format()
+        torch.cuda.empty_cache()

@@ -500,6 +500,41 @@ def test_select_lists_ties_fallback_and_edges(ops):
             ops.select_lists(x, 6, mode)
 
 
+@pytest.mark.parametrize("Bn,L,d,F,k,fp16", [(300, 2, 128, 512, 8, False), (256, 1, 64, 1024, 16, False), (1000, 3, 192, 2048, 16, False),
+                                             (513, 2, 768, 4096, 32, False), (260, 2, 72, 1024, 4, True), (64, 12, 768, 2048, 64, False)])
+def test_encoder_fused_with_per_row_selection_autocast_order(ops, Bn, L, d, F, k, fp16):
+    """PerLayerTopK lists from the encoder GEMM's row-select epilogue (row bounds from a 1/16 feature sample, candidates filed
+    per row, exact selection on those) == the lists of the unfused path (encoder GEMM -> clt_select_lists_f32 rows mode),
+    array by array: including rows with nothing positive, rows of equal values (ties by lowest index), a sample offset that
+    rotates, edge tiles; and an attempt whose bounds cannot hold must say so and emit nothing."""
+    from crosslayer_transcoder_amd import precision
+    with precision("16-mixed" if fp16 else "bf16-mixed"):
+        ops.sync_operand_format()
+        dt = ops.op16()
+        xs = _rand(Bn, L, d, seed=1)
+        Wt = _rand(L, F, d, seed=2, scale=d ** -0.5)
+        b = _rand(L, F, seed=3, scale=0.1)
+        xs[5] = 0.0                                   # pre = bias: ordinary row
+        Wt[0, 64:128] = 0.0; b[0, 64:128] = 0.7       # 64 equal values in every layer-0 row: ties at or above the k-th value
+        xs16, Wt16 = xs.to(DEV).to(dt), Wt.to(DEV).to(dt)
+        for trial, (bias, offset) in enumerate(((b, 0), (b, 5), (b - 3.0, 11), (None, 3))):      # b - 3: most rows have < k positives
+            bd = bias.to(DEV) if bias is not None else None
+            assert ops.encoder_select_rows_applicable(Bn, L, d, F, k)
+            want = ops.select_lists(ops.encoder_fwd(xs16, Wt16, bd), k, ops.SELECT_ROWS)
+            got = ops.encoder_select_rows_lists(xs16, Wt16, bd, k, offset=offset)
+            assert got.confirm(), f"trial {trial}: the attempt should hold"
+            _lists_equal(got, want, f"fused rows trial {trial}")
+        odds = ops.ROWS_FAIL_ODDS
+        try:                                          # bound = the sample's maximum: above the k-th value in about a third of the rows
+            ops.ROWS_FAIL_ODDS = 0.999
+            got = ops.encoder_select_rows_lists(xs16, Wt16, b.to(DEV), k, offset=0)
+            if k > 1:
+                assert not got.confirm() and int(got.total) == 0 and int(got.row_start[-1]) == 0
+        finally:
+            ops.ROWS_FAIL_ODDS = odds
+    ops.sync_operand_format()
+
+
 @pytest.mark.parametrize("Bn,L,d,F", [(300, 2, 128, 520), (256, 1, 64, 256), (1000, 3, 192, 1028), (513, 2, 768, 260),
                                       (300, 2, 72, 520), (260, 1, 200, 300), (256, 2, 104, 256), (270, 1, 8, 256)])
 def test_gemm_nt_fast_path(ops, Bn, L, d, F):

@@ -312,6 +312,48 @@ def test_fused_encoder_select_equals_unfused(nl_kind):
         assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
 
 
+def test_fused_encoder_rows_select_equals_unfused():
+    """PerLayerTopK, bf16, base loss: every step takes the encoder GEMM with the per-row selection in its epilogue (no
+    pre-activation tensor); the trajectory must equal the unfused path exactly, and a void attempt (bounds that cannot hold)
+    reruns the step unfused with the same result."""
+    import crosslayer_transcoder_amd.engine as E
+    from crosslayer_transcoder_amd import ops, precision
+    from tests.build_cases import build_module
+    B, L, d, F = 512, 3, 128, 512
+    g = torch.Generator().manual_seed(12)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(4)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "topk", "k": 8}, "loss": {"kind": "base"}},
+            "opt": {"lr": 1e-3}, "batches": torch.stack(batches), "init_params": params,
+            "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+    results = {}
+    odds = ops.ROWS_FAIL_ODDS
+    for fuse in (True, False):
+        E.FUSE_ENCODER_ROWS = fuse
+        E.STATS["select_fallbacks"] = 0
+        try:
+            mod = build_module(case)
+            opt = mod.configure_optimizers()
+            losses, fused_steps = [], 0
+            with precision("bf16-mixed"):
+                for t, b in enumerate(batches):
+                    ops.ROWS_FAIL_ODDS = 0.999 if (fuse and t == 2) else odds        # step 2: a void attempt, then the unfused rerun
+                    losses.append(float(mod.fused_train_step(b.cuda(), t, opt)))
+                    fused_steps += "pre_actvs" not in dict.keys(mod.last_step)
+            results[fuse] = (losses, {k: p.detach().clone() for k, p in mod.model.named_parameters()}, fused_steps,
+                             E.STATS["select_fallbacks"])
+        finally:
+            E.FUSE_ENCODER_ROWS = True
+            ops.ROWS_FAIL_ODDS = odds
+    assert results[True][2] == 3 and results[True][3] == 1 and results[False][2] == 0, results[True][2:]
+    assert results[True][0] == results[False][0]
+    for k, p in results[True][1].items():
+        assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
+
+
 def test_pinned_prefetcher_and_fit_loop(golden):
     """Batch ingest edge: double-buffered pinned H2D yields exactly the host batches (pinned and pageable sources, fp16
     and fp32), and trainer.fit on the debug-cpu golden reproduces the reference loss curve through it."""
