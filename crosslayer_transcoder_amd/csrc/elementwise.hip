@@ -482,7 +482,7 @@ __device__ __forceinline__ void ft_store_pair(uint32_t (*tile)[FT_PITCH], int p,
     q[1] = make_uint2(pack16<F16>(a[2], b[2]), pack16<F16>(a[3], b[3]));
 }
 // TILE_NT (bit 0 loads, bit 1 stores): the activation streams of the tile passes as non-temporal accesses.  Measured SLOWER
-// (PLT JumpReLU dense 19.9 ms -> 20.0 with loads, 20.4 with stores, scripts/gpu_tilent_ab.sh): what these passes write is the
+// (PLT JumpReLU dense 19.9 ms -> 20.0 with loads, 20.4 with stores, scripts/archive/gpu_tilent_ab.sh): what these passes write is the
 // next GEMM's operand and what they read the last GEMM's result, and part of it is still in the memory-side cache; unlike the
 // row pass's weight streams and the GEMMs' C tiles, where the hint pays.  Off.
 #ifndef TILE_NT
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
     float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (bias && cin) bb = *reinterpret_cast<const float4*>(bias + col);
     bool any[4] = {false, false, false, false};
-// (variants measured at B*L*F = 1.61 G, bf16 in, scripts/jf_probe.py: 2 / 4 / 8 row pairs ahead 1966 / 1996 / 1987 us, 16-byte
+// (variants measured at B*L*F = 1.61 G, bf16 in, scripts/archive/jf_probe.py: 2 / 4 / 8 row pairs ahead 1966 / 1996 / 1987 us, 16-byte
 // row stores by lane exchange 1997 us: the pass writes twice what it reads and sits at ~4.9 TB/s either way)
 #ifndef JF_AHEAD
 #define JF_AHEAD 2
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 // its 64 rows, so a row's norm is one wave's fixed-order sum.  rows % 8 == 0, n % 4 == 0.
 // GATHER: output row r of group g is input row ridx[g * rows + r] of the group's src_rows input rows (< 0: a zero row) — the
 // compacted TopK-aux pass preps the dead rows of the decoder matrices without a gathered fp32 copy in between.
-// (occupancy hints, measured as variants — scripts/gpu_waves_ab.sh: weight_prep at 2 / 3 / 4 waves per SIMD 617 / 795 / 1070 us
+// (occupancy hints, measured as variants — scripts/archive/gpu_waves_ab.sh: weight_prep at 2 / 3 / 4 waves per SIMD 617 / 795 / 1070 us
 // per PLT decoder, the tighter register budgets spill; the JumpReLU loss pass at 3 / 4: PLT step 21.5 / 22.1 ms)
 #ifndef WP_WAVES
 #define WP_WAVES 2

@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 // GEMM_NT_STORE: the C tiles leave as non-temporal stores (written once, not read again by the kernel: they do not displace the
-// operand panels from L2): PLT JumpReLU dense 20.3 -> 20.0 ms, TopK + aux 28.9 -> 28.5 ms, scripts/gpu_gemmnt_ab.sh
+// operand panels from L2): PLT JumpReLU dense 20.3 -> 20.0 ms, TopK + aux 28.9 -> 28.5 ms, scripts/archive/gpu_gemmnt_ab.sh
 #ifndef GEMM_NT_STORE
 #define GEMM_NT_STORE 1
 #endif

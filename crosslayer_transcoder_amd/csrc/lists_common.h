@@ -65,7 +65,7 @@ __global__ __launch_bounds__(LTPB) void count_rows_kernel(const void* __restrict
 // Lists in the vector form, ROWS_PER_BLOCK rows of ONE layer per block (tokens b0 .. b0 + 3): four row loads in flight per
 // lane, and the layer's thresholds (TH) are read once for four rows.  With one row per block the fp32 thresholds re-read from L2 for every row are twice the bytes
 // of a 16-bit row: count + fill took 0.76 + 0.79 ms for 3.2 GB of pre-activations against 0.55 + 0.55 without thresholds
-// (scripts/build_probe.py).  Same per-wave segments, counts and entry order as count_rows_kernel / fill_rows_kernel.
+// (scripts/archive/build_probe.py).  Same per-wave segments, counts and entry order as count_rows_kernel / fill_rows_kernel.
 constexpr int ROWS_PER_BLOCK = 4;
 __device__ __forceinline__ uint32_t rows_hits(const float4 x, const float4 t) {
     return (uint32_t)(x.x > 0.0f && x.x > t.x) + (uint32_t)(x.y > 0.0f && x.y > t.y) + (uint32_t)(x.z > 0.0f && x.z > t.z) +

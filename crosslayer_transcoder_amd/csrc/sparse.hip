@@ -23,7 +23,7 @@ constexpr int TPB = 256;
 // forward gather: one wave per (token, target layer)
 // ------------------------------------------------------------------------------------------------
 // FWD_U: gathered rows in flight per wave for d <= 768.  4, 8 and 16 measured the same (15.39 / 15.39 / 15.39 ms headline,
-// scripts/gpu_fwdu_ab.sh): the gather is not latency-bound at 4
+// scripts/archive/gpu_fwdu_ab.sh): the gather is not latency-bound at 4
 #ifndef FWD_U
 #define FWD_U 4
 #endif
@@ -149,7 +149,7 @@ struct RowPassArgs {
 #define RP_HU 3
 #endif
 // RP_TAIL2: a remainder of two entries after the batches of RP_HU is requested together as well (the TopK lists' columns hold
-// ~2 entries: headline launch 806 -> 791 us, 15.04 -> 14.83 ms, scripts/gpu_tail2_ab.sh)
+// ~2 entries: headline launch 806 -> 791 us, 15.04 -> 14.83 ms, scripts/archive/gpu_tail2_ab.sh)
 #ifndef RP_TAIL2
 #define RP_TAIL2 1
 #endif
@@ -161,7 +161,7 @@ __device__ __forceinline__ void rp_acc4(float* __restrict__ g4, float& dot, floa
 }
 // RP_NT (bit 0 loads, bit 1 stores): the weight / moment streams of the row pass (read once, written once per step) as
 // non-temporal accesses, so that they do not displace the gathered source rows ([B, L, d], 75 MB at G32 in bf16) from the
-// caches.  Headline launch 829 -> 815 us (loads) -> 812 us (loads + stores; stores alone 835), scripts/gpu_rpnt_ab.sh
+// caches.  Headline launch 829 -> 815 us (loads) -> 812 us (loads + stores; stores alone 835), scripts/archive/gpu_rpnt_ab.sh
 #ifndef RP_NT
 #define RP_NT 3
 #endif
@@ -620,7 +620,7 @@ __device__ __forceinline__ void row_pass_body(const RowPassArgs& a, const int r)
 
 template <int NT, bool VEC, int CW, bool F16 = false, bool SQ = false>
 // (about 100 registers: 4 waves per SIMD.  Forcing 5 or 6 with amdgpu_waves_per_eu spills 60 / 132 bytes per lane and the headline
-// launch goes from 787 to 971 / 1607 us, scripts/gpu_rpwaves_ab.sh)
+// launch goes from 787 to 971 / 1607 us, scripts/archive/gpu_rpwaves_ab.sh)
 __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPassArgs a) {
     row_pass_body<NT, VEC, CW, F16, SQ>(a, CW == 1 ? blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x);
 }

@@ -129,7 +129,7 @@ PIPELINE_EXCHANGE = True
 #: a share of the B*L*F entries that are active (L0 / F).  Below it the decoder forward is a row gather and the decoder
 #: weight gradient + Adam one fused row pass; above it (e.g. an untrained JumpReLU at theta = 0.03: ~45 % active) the
 #: MFMA GEMMs are cheaper.  The count is taken on the device (list construction); one host read of its overflow flag.
-#: Measured (scripts/gpu_breakeven.sh, B = 4096, F = 32768, bf16): list step = 14.9 ms + 2.4 ms per 0.1 % active (PLT) /
+#: Measured (scripts/archive/gpu_breakeven.sh, B = 4096, F = 32768, bf16): list step = 14.9 ms + 2.4 ms per 0.1 % active (PLT) /
 #: 37.4 + 11.4 (CLT) against 19.8 / 61.5 ms dense: both cross at ~0.2 % active, i.e. L0 ~ 65 features per token and layer.
 LIST_MAX_DENSITY = 1.0 / 512
 #: list regime with the fused optimizer: the Adam row passes write each updated decoder row's squared length, which is
