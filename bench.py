@@ -422,6 +422,10 @@ def main():
                        mod.last_step.get("lists")),
                    "loss": float(mod.last_step["loss"])},
     }
+    ms_ = torch.cuda.memory_stats(device)
+    line["config"]["hbm"] = {"peak_allocated_gb": round(ms_.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2),
+                             "peak_reserved_gb": round(ms_.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
+                             "alloc_retries": int(ms_.get("num_alloc_retries", 0))}
     if skew is not None:
         S_ = mod.last_step.get("lists")
         if S_ is not None:

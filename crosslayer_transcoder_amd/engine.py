@@ -502,6 +502,19 @@ def agree_on_overflow(shard, flag):
         flag.copy_(shard.all_reduce_sum(flag.clone()))
 
 
+def _rows_fit(mod, Bn, L, d, F, k, dev) -> bool:
+    """HBM headroom for the fused per-row selection: asked once per module and shape, at its second step (the first step
+    creates the optimizer state, bf16 shadows and workspaces that the answer depends on)."""
+    key = (Bn, L, d, F, k)
+    st = getattr(mod, "_rows_fit_state", None)
+    if st is None or st[0] != key:
+        mod._rows_fit_state = (key, None)
+        return False                                 # (first step of this shape: unfused)
+    if st[1] is None:
+        mod._rows_fit_state = (key, ops.encoder_select_rows_fits(Bn, L, d, F, k, dev))
+    return mod._rows_fit_state[1]
+
+
 def _list_capacity(nl, Bn, L, F):
     """Upper bound on the number of positive entries a TopK-family module leaves."""
     return max(1, min(nl.k, F) * Bn * L)
@@ -638,7 +651,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     rows_unfused = getattr(mod, "_rows_unfused_once", False)       # (the rerun after a void per-row attempt)
     mod._rows_unfused_once = False
     if (S is None and sparse and bf16 and kind in ("base", "topk") and isinstance(nl, PerLayerTopK) and shard is None and FUSE_ENCODER_ROWS
-            and not rows_unfused and ops.encoder_select_rows_applicable(Bn, L, d, F, nl.k)):
+            and not rows_unfused and ops.encoder_select_rows_applicable(Bn, L, d, F, nl.k) and _rows_fit(mod, Bn, L, d, F, nl.k, dev)):
         # per-row TopK without the pre-activation tensor: lower bound of every row from a narrow GEMM on a rotating 1/16 sample
         # of the features, candidates filed per row by the full GEMM's epilogue, exact selection on those
         def _spec_rows(S_):

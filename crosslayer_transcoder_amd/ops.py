@@ -1151,6 +1151,21 @@ def encoder_select_rows_applicable(Bn: int, L: int, d: int, F: int, k: int) -> b
             and Bn * L * F < 2 ** 32)
 
 
+def encoder_select_rows_fits(Bn: int, L: int, d: int, F: int, k: int, device, margin: float = 0.04) -> bool:
+    """Is there HBM for the fused per-row selection's scratch (slot blocks of 8 KB per row + the sampled pre-activations) with
+    `margin` of the device's memory to spare?  A model that fills the card (Llama-3-8B shape on one GPU: 283 of 288 GB) is
+    better off unfused: measured there, the step with the extra 1.3 GB ran 404 instead of 228 ms — the allocator at its limit."""
+    plan = _rows_plan(k)
+    if plan is None:
+        return False
+    j, slots = plan
+    need = lib.clt_select_rows_ext_workspace_bytes(Bn, L, F, k, slots, F // ROWS_SAMPLE_STRIDE, j) + 4 * Bn * L * (F // ROWS_SAMPLE_STRIDE)
+    free, total = torch.cuda.mem_get_info(device)
+    st = torch.cuda.memory_stats(device)
+    free += st.get("reserved_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)      # (torch's cached, unused blocks)
+    return free - need >= margin * total
+
+
 def encoder_select_rows_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.Tensor], k: int, offset: int = 0,
                               speculate=None) -> SparseLists:
     """Encoder forward fused with the PerLayerTopK selection (topk.py:53-63): the pre-activation tensor is never written.

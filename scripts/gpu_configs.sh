@@ -10,7 +10,7 @@ run --steps 10 --warmup 3 --nonlinearity jumprelu --decoder plt
 run --steps 10 --warmup 3 --nonlinearity jumprelu --decoder plt --batch 8192
 run --steps 5 --warmup 2 --nonlinearity jumprelu --decoder clt
 run --steps 5 --warmup 2 --nonlinearity jumprelu --decoder clt --layers 16 --d-acts 2048 --features 8192
-run --steps 5 --warmup 2 --nonlinearity topk --aux --layers 32 --d-acts 4096 --features 8192 --distinct-batches 2
+run --steps 5 --warmup 2 --nonlinearity topk --aux --layers 32 --d-acts 4096 --features 8192 --distinct-batches 1
 # the shapes of the reference's own YAML files (config/default.yaml: JumpReLU CLT, F=10000/layer, batch 4000;
 # config/topk-clt.yaml: PerLayerTopK(16) + aux(512), F=20000/layer, batch 2000)
 run --steps 10 --warmup 3 --nonlinearity jumprelu --features 10000 --batch 4000

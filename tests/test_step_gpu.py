@@ -313,7 +313,7 @@ def test_fused_encoder_select_equals_unfused(nl_kind):
 
 
 def test_fused_encoder_rows_select_equals_unfused():
-    """PerLayerTopK, bf16, base loss: every step takes the encoder GEMM with the per-row selection in its epilogue (no
+    """PerLayerTopK, bf16, base loss: from the second step on the encoder GEMM carries the per-row selection in its epilogue (no
     pre-activation tensor); the trajectory must equal the unfused path exactly, and a void attempt (bounds that cannot hold)
     reruns the step unfused with the same result."""
     import crosslayer_transcoder_amd.engine as E
@@ -348,7 +348,8 @@ def test_fused_encoder_rows_select_equals_unfused():
         finally:
             E.FUSE_ENCODER_ROWS = True
             ops.ROWS_FAIL_ODDS = odds
-    assert results[True][2] == 3 and results[True][3] == 1 and results[False][2] == 0, results[True][2:]
+    # (step 0 runs unfused: the HBM headroom is asked once the optimizer state exists; step 2 is the void attempt)
+    assert results[True][2] == 2 and results[True][3] == 1 and results[False][2] == 0, results[True][2:]
     assert results[True][0] == results[False][0]
     for k, p in results[True][1].items():
         assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
