@@ -417,9 +417,9 @@ __global__ __launch_bounds__(LTPB) void fill_cols_kernel(const uint32_t* __restr
     }
 }
 
-// order each column's entries by token.  Short columns: one thread, insertion sort.  Long columns are
-// queued and sorted by a block (bitonic in LDS) in sort_long_cols_kernel.
-constexpr int SHORT_COL = 24, LONGCOL_MAX = 4096;
+// order each column's entries by token.  Short columns: one thread, insertion sort.  Longer columns are queued for
+// sort_long_cols_kernel: up to MIDCOL_MAX entries one wave per column (rank counting), beyond that a block (bitonic in LDS).
+constexpr int SHORT_COL = 24, MIDCOL_MAX = 1024, LONGCOL_MAX = 4096;
 __global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int ncols, int32_t* __restrict__ tok,
                                  float* __restrict__ val, int32_t* __restrict__ ent, int32_t* __restrict__ long_list,
                                  uint32_t* __restrict__ long_count, const int32_t* __restrict__ gate, int gate_on) {
@@ -446,9 +446,46 @@ __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __
     __shared__ float sval[LONGCOL_MAX];
     __shared__ int32_t sent[LONGCOL_MAX];
     const uint32_t nl = *long_count;
+    // columns of up to MIDCOL_MAX entries: one WAVE each, no block barrier — the keys of a list are distinct (a token / a column
+    // occurs once), so an entry's place is the number of smaller keys: every lane counts that for its (up to 16) entries
+    // against the list, read key by key from the wave's LDS copy, and stores them straight to their places
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        int32_t* wtok = reinterpret_cast<int32_t*>(key) + wv * MIDCOL_MAX;
+        for (uint32_t q = blockIdx.x * (LTPB / 64) + wv; q < nl; q += gridDim.x * (LTPB / 64)) {
+            const int c = long_list[q];
+            const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+            if (n > MIDCOL_MAX) continue;
+            const int E = (int)((n + 63) >> 6);
+            int32_t t[MIDCOL_MAX / 64], en[MIDCOL_MAX / 64];
+            float v[MIDCOL_MAX / 64];
+            uint32_t rank[MIDCOL_MAX / 64];
+#pragma unroll
+            for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+                const uint32_t i = (uint32_t)e * 64 + lane;
+                rank[e] = 0;
+                if (e < E && i < n) { t[e] = tok[s + i]; v[e] = val[s + i]; en[e] = ent ? ent[s + i] : 0; wtok[i] = t[e]; }
+                else t[e] = 0x7fffffff;
+            }
+            __builtin_amdgcn_wave_barrier();               // (the copy is this wave's own: LDS serves a wave's accesses in order)
+            for (uint32_t j = 0; j < n; ++j) {
+                const int32_t tj = wtok[j];
+#pragma unroll
+                for (int e = 0; e < MIDCOL_MAX / 64; ++e) if (e < E) rank[e] += tj < t[e] ? 1u : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+                const uint32_t i = (uint32_t)e * 64 + lane;
+                if (e < E && i < n) { tok[s + rank[e]] = t[e]; val[s + rank[e]] = v[e]; if (ent) ent[s + rank[e]] = en[e]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
     for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
         const int c = long_list[q];
         const uint32_t s = col_start[c], n = col_start[c + 1] - s;
+        if (n <= MIDCOL_MAX) continue;                  // (done above)
         if (n > LONGCOL_MAX) continue;                  // left in arrival order (still correct, not bit-reproducible)
         uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
         for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {

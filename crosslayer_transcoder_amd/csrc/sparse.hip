@@ -192,7 +192,8 @@ __device__ __forceinline__ void rp_st2(uint16_t* q, uint32_t a, uint32_t b) {
 // few extra instructions cost the headline launch 20 us (830 -> 851, register allocation of the whole body moved)
 // The entries [p, pend) of one list of column `col` (a whole column, or one wave's segment of a hot column): gradient sums into
 // g, dots written, coefficient sum into csum.  p0 = first entry of the column (parity of the CW > 1 dot exchange).
-template <int NT, bool VEC, int CW, bool F16>
+// HU: source rows requested together (6 in the hot-row kernel spills under its 128-register budget and gains nothing: 3 everywhere; the sums do not depend on it)
+template <int NT, bool VEC, int CW, bool F16, int HU = RP_HU>
 __device__ __forceinline__ void row_pass_walk(const RowPassArgs& a, const int pass, const int col, const int layer, const int lane, const int wave,
                                               const int cb, uint32_t p, const uint32_t pend, const uint32_t p0, const float (&wv)[NT][VEC ? 4 : 1],
                                               float (&g)[NT][VEC ? 4 : 1], float& csum, float (*shdot)[CW]) {
@@ -242,7 +243,8 @@ __device__ __forceinline__ void row_pass_walk(const RowPassArgs& a, const int pa
             }
             p += NU;
         };
-        while (p + RP_HU <= pend) batch(std::integral_constant<int, RP_HU>{});
+        while (p + HU <= pend) batch(std::integral_constant<int, HU>{});
+        if constexpr (HU > RP_HU) { if (p + RP_HU <= pend) batch(std::integral_constant<int, RP_HU>{}); }
 #if RP_HU > 2 && RP_TAIL2
         if (p + 2 <= pend) batch(std::integral_constant<int, 2>{});      // (a remainder of two: together as well)
 #endif
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(CW == 1 ? TPB : 64 * CW) void row_pass_kernel(RowPa
 // pointers, source and layer.  On a feature shard the per-matrix launches are 35..180 us long and spend a fifth of that
 // ramping up and draining.
 constexpr int RP_GROUP_MAX = 16;
-constexpr int HOT_GRID = 512;                             // blocks of row_pass_hot_kernel (each walks the hot list with this stride)
+constexpr int HOT_GRID = 1024;                            // blocks of the hot-row kernels (each walks its table with this stride)
 struct RowPassGroup {
     int n; int row_end[RP_GROUP_MAX];                     // cumulative row counts
     float* W[RP_GROUP_MAX]; float* m[RP_GROUP_MAX]; float* v[RP_GROUP_MAX]; uint16_t* shadow[RP_GROUP_MAX];
@@ -653,24 +655,51 @@ __global__ __launch_bounds__(TPB) void row_pass_group_kernel(RowPassArgs a, RowP
 // ---- heavy-tailed feature frequencies ------------------------------------------------------------------------------
 // A feature that fires in 10 % of the tokens is a 400-entry list, which one wave of row_pass_kernel would walk alone
 // while the rows around it finish in a few entries.  Columns longer than `hot_min_len` are therefore listed once per step
-// (hot_columns_kernel) and their rows go through row_pass_hot_kernel: one block of HW waves per row, wave w walks the
-// w-th contiguous segment of the list (dots are per entry and written directly; the gradient sums of the segments are
-// combined through LDS in wave order: a fixed summation order, as everywhere), wave 0 finishes the row (Adam).
+// (hot_columns_kernel) and left out by the common pass.  Their lists are walked in SEGMENTS by row_pass_seg_kernel (a block of
+// HW waves per segment, a wave per piece of it; dots are per entry and written directly; the pieces' gradient sums are
+// combined through LDS in wave order and the segment's sum goes to scratch), and row_pass_hot_kernel (a wave per row) adds a
+// row's segment sums in segment order and finishes the row (Adam): a fixed summation order, as everywhere.
+// The hot block (int32 [6 * cap]): [0, cap) the hot columns | [cap, 2 cap) per hot column its first SEGMENT slot (-1: no room in
+// the table, the column is walked whole) | [2 cap, 6 cap) the segment table, 2 cap pairs (hot index, segment); hot_count[0] = hot
+// columns, hot_count[1] = segments.  Every hot column is cut into segments of HOT_SEG entries, each walked by a block of its
+// own (row_pass_seg_kernel): equal work items whatever the column lengths — a feature that fires in half of the tokens is 2000
+// entries, which the waves of ONE block would walk for ~100 us while the chip waits for that block.
+// cap >= entries / (min_len + 1) + 1 bounds the hot columns; segments <= entries / HOT_SEG + hot columns ~ 2 cap.
+constexpr int HOT_SEG = 64;
 __global__ void hot_columns_kernel(const uint32_t* __restrict__ col_start, int ncols, uint32_t min_len, int32_t* __restrict__ hot_list,
                                    uint32_t hot_cap, uint32_t* __restrict__ hot_count) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
-    if (col_start[c + 1] - col_start[c] > min_len) {
-        const uint32_t pos = atomicAdd(hot_count, 1u);
-        if (pos < hot_cap) hot_list[pos] = c;      // (hot_cap >= entries / (min_len + 1) + 1 by the caller: never exceeded)
+    const uint32_t len = col_start[c + 1] - col_start[c];
+    if (len > min_len) {
+        const uint32_t pos = atomicAdd(&hot_count[0], 1u);
+        if (pos >= hot_cap) return;                 // (hot_cap >= entries / (min_len + 1) + 1 by the caller: never exceeded)
+        hot_list[pos] = c;
+        int32_t base = -1;
+        const uint32_t nseg = (len + HOT_SEG - 1) / HOT_SEG;
+        const uint32_t b = atomicAdd(&hot_count[1], nseg);
+        if (b + nseg <= 2 * hot_cap) {
+            base = (int32_t)b;
+            for (uint32_t q = 0; q < nseg; ++q) { hot_list[2 * hot_cap + 2 * (b + q)] = (int32_t)pos; hot_list[2 * hot_cap + 2 * (b + q) + 1] = (int32_t)q; }
+        }
+        hot_list[hot_cap + pos] = base;
     }
 }
 
-template <int NT> struct HotWaves { static constexpr int value = NT <= 3 ? 16 : 8; };   // (LDS: HW * NT KB for the partial sums)
+#ifndef HOT_HU
+#define HOT_HU 3
+#endif
+template <int NT> struct HotWaves { static constexpr int value = 8; };   // waves of a segment block (LDS: HW * NT KB for the piece sums)
+// floats of one segment's partial result: the gradient row (NT x 256) + the coefficient sum
+template <int NT> struct HotPart { static constexpr int value = NT * 256 + 64; };
+
+// one block per (hot column, segment) of the segment table: the HW waves walk the segment's HW pieces (dots written per entry,
+// as everywhere), the piece sums are combined through LDS in wave order and the segment's sum goes to partials[slot]
 template <int NT, bool F16>
-__global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_hot_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
+__global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_seg_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
                                                                                const int32_t* __restrict__ hot_list,
-                                                                               const uint32_t* __restrict__ hot_count, uint32_t hot_cap) {
+                                                                               const uint32_t* __restrict__ hot_count, uint32_t hot_cap,
+                                                                               float* __restrict__ partials) {
     constexpr int HW = HotWaves<NT>::value;
     __shared__ float part[HW][NT * 256];
     __shared__ float pcs[HW];
@@ -680,25 +709,23 @@ __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_hot_kernel(
         const int i = blockIdx.y;
         a.W = grp.W[i]; a.m = grp.m[i]; a.v = grp.v[i]; a.shadow = grp.shadow[i]; a.src = grp.src[i]; a.src_layer = grp.src_layer[i];
         a.rows = grp.row_end[i] - (i ? grp.row_end[i - 1] : 0);
+        partials += (long)i * 2 * hot_cap * HotPart<NT>::value;
     }
-    const uint32_t nh = min(*hot_count, hot_cap);
-    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+    const uint32_t ns = min(hot_count[1], 2 * hot_cap);
+    for (uint32_t it = blockIdx.x; it < ns; it += gridDim.x) {
+        const int h = hot_list[2 * hot_cap + 2 * it], sg = hot_list[2 * hot_cap + 2 * it + 1];
         const int col = hot_list[h];
         const int r = col - a.col0;
         if (r < 0 || r >= a.rows) continue;                        // (block-uniform)
         const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
         float wv[NT][4], g[NT][4], mm[NT][4], vv[NT][4];
-        row_pass_load<NT, true>(a, (long)r * a.d, lane, 0, wv, g, mm, vv, wave == 0);
+        row_pass_load<NT, true>(a, (long)r * a.d, lane, 0, wv, g, mm, vv, false);
         float csum = 0.0f;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            const uint32_t* cs = pass ? a.col_start2 : a.col_start;
-            if (!cs) continue;
-            const uint32_t p0 = cs[col], p1 = cs[col + 1];
-            const uint32_t per = (p1 - p0 + HW - 1) / HW;
-            const uint32_t q0 = min(p1, p0 + (uint32_t)wave * per), q1 = min(p1, q0 + per);
-            row_pass_walk<NT, true, 1, F16>(a, pass, col, layer, lane, wave, 0, q0, q1, p0, wv, g, csum, shdot);
-        }
+        const uint32_t p0 = a.col_start[col], p1 = a.col_start[col + 1];
+        const uint32_t s0 = p0 + (uint32_t)sg * HOT_SEG, s1 = min(p1, s0 + HOT_SEG);
+        const uint32_t per = (s1 - s0 + HW - 1) / HW;
+        const uint32_t q0 = min(s1, s0 + (uint32_t)wave * per), q1 = min(s1, q0 + per);
+        row_pass_walk<NT, true, 1, F16, HOT_HU>(a, 0, col, layer, lane, wave, 0, q0, q1, p0, wv, g, csum, shdot);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             *reinterpret_cast<float4*>(&part[wave][(t * 64 + lane) * 4]) = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
@@ -706,7 +733,7 @@ __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_hot_kernel(
         __syncthreads();
         if (wave == 0) {
 #pragma unroll 1
-            for (int w = 1; w < HW; ++w) {                         // wave order: the row's fixed summation order
+            for (int w = 1; w < HW; ++w) {                         // wave order: a fixed summation order
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const float4 x = *reinterpret_cast<const float4*>(&part[w][(t * 64 + lane) * 4]);
@@ -714,9 +741,61 @@ __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_hot_kernel(
                 }
                 csum += pcs[w];
             }
-            row_pass_finish<NT, true, 1, F16, true>(a, r, col, lane, 0, 0, wv, g, mm, vv, csum);
+            float* dst = partials + (long)it * HotPart<NT>::value;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                *reinterpret_cast<float4*>(dst + (t * 64 + lane) * 4) = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
+            if (lane == 0) dst[NT * 256] = csum;
         }
         __syncthreads();
+    }
+}
+
+// the hot rows themselves, one wave each: the segments' sums are added in segment order (the row's fixed summation order), a
+// second list is walked as in the common pass, then the row is finished (Adam, shadow, squared length) as there
+template <int NT, bool F16>
+__global__ __launch_bounds__(TPB) void row_pass_hot_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
+                                                          const int32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count,
+                                                          uint32_t hot_cap, const float* __restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (use_group) {
+        const int i = blockIdx.y;
+        a.W = grp.W[i]; a.m = grp.m[i]; a.v = grp.v[i]; a.shadow = grp.shadow[i]; a.src = grp.src[i]; a.src_layer = grp.src_layer[i];
+        a.rows = grp.row_end[i] - (i ? grp.row_end[i - 1] : 0);
+        if (partials) partials += (long)i * 2 * hot_cap * HotPart<NT>::value;
+    }
+    const uint32_t nh = min(hot_count[0], hot_cap);
+    for (uint32_t h = blockIdx.x * 4 + wave; h < nh; h += gridDim.x * 4) {
+        const int col = hot_list[h];
+        const int r = col - a.col0;
+        if (r < 0 || r >= a.rows) continue;                        // (wave-uniform; nothing below synchronises the block)
+        const int layer = a.src_layer >= 0 ? a.src_layer : col / a.F;
+        const int sb = partials ? hot_list[hot_cap + h] : -1;      // >= 0: the first list was walked by row_pass_seg_kernel
+        float wv[NT][4], g[NT][4], mm[NT][4], vv[NT][4];
+        row_pass_load<NT, true>(a, (long)r * a.d, lane, 0, wv, g, mm, vv, true);
+        float csum = 0.0f;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t* cs = pass ? a.col_start2 : a.col_start;
+            if (!cs) continue;
+            const uint32_t p0 = cs[col], p1 = cs[col + 1];
+            if (pass == 0 && sb >= 0) {
+                const uint32_t nseg = (p1 - p0 + HOT_SEG - 1) / HOT_SEG;
+#pragma unroll 1
+                for (uint32_t q = 0; q < nseg; ++q) {
+                    const float* src = partials + (long)(sb + q) * HotPart<NT>::value;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 x = *reinterpret_cast<const float4*>(src + (t * 64 + lane) * 4);
+                        g[t][0] += x.x; g[t][1] += x.y; g[t][2] += x.z; g[t][3] += x.w;
+                    }
+                    csum += src[NT * 256];
+                }
+                continue;
+            }
+            row_pass_walk<NT, true, 1, F16>(a, pass, col, layer, lane, 0, 0, p0, p1, p0, wv, g, csum, nullptr);
+        }
+        row_pass_finish<NT, true, 1, F16, true>(a, r, col, lane, 0, 0, wv, g, mm, vv, csum);
     }
 }
 
@@ -920,7 +999,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
                             const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
                             const float* row_sq, float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap,
-                            int hot_min_len, void* stp) {
+                            int hot_min_len, float* hot_partials, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
@@ -977,8 +1056,12 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
         RowPassGroup none = {};
 #define RPH(NT_)                                                                                                          \
     do {                                                                                                                    \
-        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap); \
-        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap); \
+        if (hot_partials) {                                                                                                 \
+            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_partials); \
+            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_partials); \
+        }                                                                                                                   \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
     } while (0)
         if (chunks <= 1) RPH(1); else if (chunks <= 2) RPH(2); else if (chunks <= 3) RPH(3); else RPH(4);
 #undef RPH
@@ -989,7 +1072,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
 int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap, uint32_t* hot_count,
                            void* stp) {
     if (!col_start || ncols <= 0 || min_len < 1 || !hot_list || !hot_count || hot_cap == 0) return CLT_ERR_SHAPE;
-    if (hipMemsetAsync(hot_count, 0, sizeof(uint32_t), as_stream(stp)) != hipSuccess) return CLT_ERR_LAUNCH;
+    if (hipMemsetAsync(hot_count, 0, 2 * sizeof(uint32_t), as_stream(stp)) != hipSuccess) return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(hot_columns_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), col_start, ncols, (uint32_t)min_len,
                        hot_list, hot_cap, hot_count);
     CLT_LAUNCH_CHECK(); return CLT_OK;
@@ -1000,7 +1083,7 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
                                    const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
                                    double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
                                    int src_bf16, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
-                                   void* stp) {
+                                   float* hot_partials, void* stp) {
     if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if (nmat <= 0 || d <= 0 || F <= 0 || L <= 0 || step < 1 || !W || !m || !v || !rows || !src_layer || !src) return CLT_ERR_SHAPE;
     if (nmat > RP_GROUP_MAX) return 1;
@@ -1038,8 +1121,12 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
     if (hot_list) {                                        // the hot rows of every matrix of the group: grid.y = matrix
 #define RPGH(NT_)                                                                                              \
     do {                                                                                                        \
-        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap); \
-        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap); \
+        if (hot_partials) {                                                                                     \
+            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_partials); \
+            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_partials); \
+        }                                                                                                       \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
     } while (0)
         if (chunks <= 1) RPGH(1); else if (chunks <= 2) RPGH(2); else if (chunks <= 3) RPGH(3); else RPGH(4);
 #undef RPGH

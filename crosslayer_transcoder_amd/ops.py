@@ -1331,34 +1331,46 @@ _HOT_SEEN = {}            # (device, B, L, F) -> [pinned int32 [1] with the last
 
 
 def hot_columns(s: SparseLists):
-    """(hot_list int32 [cap], hot_count int32 [1], cap) of the lists' columns longer than HOT_MIN_LEN, computed once per lists
-    object (one small kernel) and kept on it; None when switched off — or when the LAST lists of this shape on this device
-    had no such column: the count is copied to pinned memory behind the kernel and read a step later (it has long arrived: no
-    stall), and a workload without hot columns pays for neither the second launch of every row pass nor its skip test.  The
-    row passes are correct with or without the list (a hot row then takes one wave); only the summation order of hot rows
-    depends on it, and it is a deterministic function of the previous step."""
+    """(hot block int32 [6 cap], counts int32 [2], cap, scratch by stream) of the lists' columns longer than HOT_MIN_LEN (the columns, their
+    segment slots and the segment table: include/clt_hip.h), computed once per lists object (one small kernel) and kept on it;
+    None when switched off — or when the LAST lists of this shape on this device had no such column: the count is copied to
+    pinned memory behind the kernel and read a step later (it has long arrived: no stall), and a workload without hot columns
+    pays for neither the extra launches of every row pass nor its skip test.  The row passes are correct with or without the
+    list (a hot row then takes one wave); only the summation order of hot rows depends on it, and it is a deterministic
+    function of the previous step."""
     hot = getattr(s, "hot", None)
     if hot is None and HOT_MIN_LEN > 0:
         dev = s.col_start.device
         cap = s.cap // (HOT_MIN_LEN + 1) + 1                 # more hot columns than this cannot exist
-        lst = torch.empty(cap, dtype=torch.int32, device=dev)
-        cnt = torch.empty(1, dtype=torch.int32, device=dev)
+        lst = torch.empty(6 * cap, dtype=torch.int32, device=dev)
+        cnt = torch.empty(2, dtype=torch.int32, device=dev)
         call("clt_sparse_hot_columns", s.col_start.data_ptr(), s.L * s.F, HOT_MIN_LEN, lst.data_ptr(), cap, cnt.data_ptr(), _stream())
-        seen = _HOT_SEEN.setdefault((dev.index, s.B, s.L, s.F), [torch.zeros(1, dtype=torch.int32).pin_memory(), None])
+        seen = _HOT_SEEN.setdefault((dev.index, s.B, s.L, s.F), [torch.zeros(2, dtype=torch.int32).pin_memory(), None])
         enabled = True
         if seen[1] is not None:
             seen[1].synchronize()
-            enabled = int(seen[0]) > 0
+            enabled = int(seen[0][0]) > 0
         seen[0].copy_(cnt, non_blocking=True)
         seen[1] = torch.cuda.Event()
         seen[1].record()
-        hot = s.hot = (lst, cnt, cap) if enabled else False
+        hot = s.hot = (lst, cnt, cap, {}) if enabled else False
     return hot or None
 
 
-def _hot_args(s):
+def _hot_args(s, d: int = 0, nmat: int = 1):
+    """The hot-row arguments of the row pass entry points.  The segment scratch (`hot_partials`) is per stream — passes of
+    different matrices may run on two streams at once — and grows to the largest (d, nmat) asked for."""
     hot = hot_columns(s)
-    return (None, None, 0, 0) if hot is None else (hot[0].data_ptr(), hot[1].data_ptr(), hot[2], HOT_MIN_LEN)
+    if hot is None:
+        return (None, None, 0, 0, None)
+    part = None
+    if 0 < d <= 1024 and d % 4 == 0:
+        need = nmat * 2 * hot[2] * (-(-d // 256) * 256 + 64)
+        key = torch.cuda.current_stream().cuda_stream
+        part = hot[3].get(key)
+        if part is None or part.numel() < need:
+            part = hot[3][key] = torch.empty(need, dtype=torch.float32, device=s.col_start.device)
+    return (hot[0].data_ptr(), hot[1].data_ptr(), hot[2], HOT_MIN_LEN, part.data_ptr() if part is not None else None)
 
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
@@ -1404,7 +1416,7 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), ptr(sq_out), *_hot_args(s), _stream())
+         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), ptr(sq_out), *_hot_args(s, d), _stream())
 
 
 def sparse_row_pass_group(Ws, s: SparseLists, coef, srcs, layers, *, adam, ms, vs, shadows=None, dots=None, src_slab=False) -> bool:
@@ -1429,7 +1441,7 @@ def sparse_row_pass_group(Ws, s: SparseLists, coef, srcs, layers, *, adam, ms, v
                     ptrs(shadows) if shadows is not None else None, rows, (C.c_int * n)(*layers), sp, d, s.F, src_L, s.col_start.data_ptr(),
                     s.csc_tok.data_ptr(), _chk(coef).data_ptr(), dots.data_ptr() if dots is not None else None, s.cap, float(adam["lr"]),
                     float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"]), float(adam["weight_decay"]), int(adam["adamw"]),
-                    int(adam["step"]), int(src_bf16), *_hot_args(s), _stream())
+                    int(adam["step"]), int(src_bf16), *_hot_args(s, d, n), _stream())
     if rc == 1:
         return False
     if rc != 0:

@@ -414,6 +414,37 @@ def _lists_equal(A, Bl, what):
         assert torch.equal(getattr(A, name)[:n], getattr(Bl, name)[:n]), f"{what}: {name}"
 
 
+def test_list_columns_and_rows_are_ordered_at_every_length(ops):
+    """The feature-major lists hold every column's entries in ascending token order and the token-major lists every row's in
+    ascending column order, whatever the length: up to 24 entries one thread orders them, up to 1024 one wave (rank counting),
+    beyond that a block (bitonic) — checked entry by entry against the dense tensor the lists were built from."""
+    B, L, F = 3000, 2, 96
+    g = torch.Generator().manual_seed(3)
+    dens = torch.tensor([0.0, 0.002, 0.007, 0.02, 0.1, 0.3, 0.34, 0.5, 0.9, 1.0]).repeat_interleave(10)[:F]      # column lengths 0 .. 3000
+    x = (torch.rand(B, L, F, generator=g) < dens).float() * (torch.rand(B, L, F, generator=g) + 0.1)
+    x[:, 1, :48] = 0.0
+    x[7] = torch.rand(L, F, generator=g) + 0.1                                 # a full row (96 entries per layer)
+    xd = x.to(DEV)
+    S = ops.sparse_build(xd, int((x > 0).sum()))
+    n = int(S.total)
+    assert n == int((x > 0).sum()) and int(S.overflow) == 0
+    cs, tok, val = S.col_start.cpu().long(), S.csc_tok.cpu().long()[:n], S.csc_val.cpu()[:n]
+    lens = cs[1:] - cs[:-1]
+    assert int(lens.max()) == B and int(((lens > 24) & (lens <= 1024)).sum()) > 10 and int((lens > 1024).sum()) > 10
+    col = torch.repeat_interleave(torch.arange(L * F), lens)
+    same_col = col[1:] == col[:-1]
+    assert bool((tok[1:][same_col] > tok[:-1][same_col]).all()), "tokens of a column must ascend"
+    assert torch.equal(val, x.reshape(B, L * F)[tok, col])
+    ent = S.csc_ent.cpu().long()[:n]
+    assert torch.equal(S.ent_val.cpu()[:n][ent], val) and torch.equal(S.ent_col.cpu().long()[:n][ent], col)
+    rs, ecol = S.row_start.cpu().long(), S.ent_col.cpu().long()[:n]
+    rlen = rs[1:] - rs[:-1]
+    row = torch.repeat_interleave(torch.arange(B * L), rlen)
+    same_row = row[1:] == row[:-1]
+    assert bool((ecol[1:][same_row] > ecol[:-1][same_row]).all()), "columns of a row must ascend"
+    assert torch.equal(S.ent_val.cpu()[:n], x.reshape(B, L * F)[row // L, ecol])
+
+
 @pytest.mark.parametrize("x16", [False, True], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("B,L,F", [(37, 3, 264), (8, 2, 4096), (5, 1, 1028), (2, 4, 32768), (9, 2, 30)])
 def test_threshold_lists_equal_lists_of_the_thresholded_tensor(ops, B, L, F, x16):
