@@ -94,11 +94,11 @@ SIGNATURES = {
                                      P, P, SZ, P]),
     "clt_sparse_decoder_fwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, C.c_uint32, I, L, L, I, I, P]),
     "clt_sparse_row_pass_group_f32": (I, [I, P, P, P, P, P, P, P, I, I, I, P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double,
-                                          C.c_double, I, I, I, P, P, C.c_uint32, I, P, P]),
+                                          C.c_double, I, I, I, P, P, C.c_uint32, I, C.c_uint32, P, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P, P, P,
-                                    P, P, C.c_uint32, I, P, P]),
-    "clt_sparse_hot_columns": (I, [P, I, I, P, C.c_uint32, P, P]),
+                                    P, P, C.c_uint32, I, C.c_uint32, P, P]),
+    "clt_sparse_hot_columns": (I, [P, I, I, P, C.c_uint32, C.c_uint32, P, P]),
     "clt_compact_columns": (I, [P, I, I, I, P, P, P, P]),
     "clt_gather_cols_f32": (I, [P, P, I, I, I, I, F32, P, P]),
     "clt_gather_rows_f32": (I, [P, P, I, I, I, I, P, P]),

@@ -659,15 +659,15 @@ __global__ __launch_bounds__(TPB) void row_pass_group_kernel(RowPassArgs a, RowP
 // HW waves per segment, a wave per piece of it; dots are per entry and written directly; the pieces' gradient sums are
 // combined through LDS in wave order and the segment's sum goes to scratch), and row_pass_hot_kernel (a wave per row) adds a
 // row's segment sums in segment order and finishes the row (Adam): a fixed summation order, as everywhere.
-// The hot block (int32 [6 * cap]): [0, cap) the hot columns | [cap, 2 cap) per hot column its first SEGMENT slot (-1: no room in
-// the table, the column is walked whole) | [2 cap, 6 cap) the segment table, 2 cap pairs (hot index, segment); hot_count[0] = hot
-// columns, hot_count[1] = segments.  Every hot column is cut into segments of HOT_SEG entries, each walked by a block of its
+// The hot block (int32 [2 cap + 2 seg_cap]): [0, cap) the hot columns | [cap, 2 cap) per hot column its first SEGMENT slot (-1: no
+// room in the table, the column is walked whole) | then the segment table, seg_cap pairs (hot index, segment); hot_count[0] =
+// hot columns, hot_count[1] = segments asked for (may exceed seg_cap).  Every hot column is cut into segments of HOT_SEG entries, each walked by a block of its
 // own (row_pass_seg_kernel): equal work items whatever the column lengths — a feature that fires in half of the tokens is 2000
 // entries, which the waves of ONE block would walk for ~100 us while the chip waits for that block.
-// cap >= entries / (min_len + 1) + 1 bounds the hot columns; segments <= entries / HOT_SEG + hot columns ~ 2 cap.
+// cap >= entries / (min_len + 1) + 1 bounds the hot columns; segments <= entries / HOT_SEG + hot columns (the caller sizes seg_cap).
 constexpr int HOT_SEG = 64;
 __global__ void hot_columns_kernel(const uint32_t* __restrict__ col_start, int ncols, uint32_t min_len, int32_t* __restrict__ hot_list,
-                                   uint32_t hot_cap, uint32_t* __restrict__ hot_count) {
+                                   uint32_t hot_cap, uint32_t seg_cap, uint32_t* __restrict__ hot_count) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     const uint32_t len = col_start[c + 1] - col_start[c];
@@ -678,7 +678,7 @@ __global__ void hot_columns_kernel(const uint32_t* __restrict__ col_start, int n
         int32_t base = -1;
         const uint32_t nseg = (len + HOT_SEG - 1) / HOT_SEG;
         const uint32_t b = atomicAdd(&hot_count[1], nseg);
-        if (b + nseg <= 2 * hot_cap) {
+        if (b + nseg <= seg_cap) {
             base = (int32_t)b;
             for (uint32_t q = 0; q < nseg; ++q) { hot_list[2 * hot_cap + 2 * (b + q)] = (int32_t)pos; hot_list[2 * hot_cap + 2 * (b + q) + 1] = (int32_t)q; }
         }
@@ -699,7 +699,7 @@ template <int NT, bool F16>
 __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_seg_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
                                                                                const int32_t* __restrict__ hot_list,
                                                                                const uint32_t* __restrict__ hot_count, uint32_t hot_cap,
-                                                                               float* __restrict__ partials) {
+                                                                               uint32_t seg_cap, float* __restrict__ partials) {
     constexpr int HW = HotWaves<NT>::value;
     __shared__ float part[HW][NT * 256];
     __shared__ float pcs[HW];
@@ -709,11 +709,12 @@ __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_seg_kernel(
         const int i = blockIdx.y;
         a.W = grp.W[i]; a.m = grp.m[i]; a.v = grp.v[i]; a.shadow = grp.shadow[i]; a.src = grp.src[i]; a.src_layer = grp.src_layer[i];
         a.rows = grp.row_end[i] - (i ? grp.row_end[i - 1] : 0);
-        partials += (long)i * 2 * hot_cap * HotPart<NT>::value;
+        partials += (long)i * seg_cap * HotPart<NT>::value;
     }
-    const uint32_t ns = min(hot_count[1], 2 * hot_cap);
+    const uint32_t ns = min(hot_count[1], seg_cap);
     for (uint32_t it = blockIdx.x; it < ns; it += gridDim.x) {
         const int h = hot_list[2 * hot_cap + 2 * it], sg = hot_list[2 * hot_cap + 2 * it + 1];
+        if (h < 0) continue;                                       // (a hole: its column was not segmented)
         const int col = hot_list[h];
         const int r = col - a.col0;
         if (r < 0 || r >= a.rows) continue;                        // (block-uniform)
@@ -756,13 +757,13 @@ __global__ __launch_bounds__(64 * HotWaves<NT>::value) void row_pass_seg_kernel(
 template <int NT, bool F16>
 __global__ __launch_bounds__(TPB) void row_pass_hot_kernel(RowPassArgs a, RowPassGroup grp, int use_group,
                                                           const int32_t* __restrict__ hot_list, const uint32_t* __restrict__ hot_count,
-                                                          uint32_t hot_cap, const float* __restrict__ partials) {
+                                                          uint32_t hot_cap, uint32_t seg_cap, const float* __restrict__ partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (use_group) {
         const int i = blockIdx.y;
         a.W = grp.W[i]; a.m = grp.m[i]; a.v = grp.v[i]; a.shadow = grp.shadow[i]; a.src = grp.src[i]; a.src_layer = grp.src_layer[i];
         a.rows = grp.row_end[i] - (i ? grp.row_end[i - 1] : 0);
-        if (partials) partials += (long)i * 2 * hot_cap * HotPart<NT>::value;
+        if (partials) partials += (long)i * seg_cap * HotPart<NT>::value;
     }
     const uint32_t nh = min(hot_count[0], hot_cap);
     for (uint32_t h = blockIdx.x * 4 + wave; h < nh; h += gridDim.x * 4) {
@@ -999,7 +1000,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
                             const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
                             const float* row_sq, float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap,
-                            int hot_min_len, float* hot_partials, void* stp) {
+                            int hot_min_len, uint32_t hot_seg_cap, float* hot_partials, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
@@ -1057,11 +1058,11 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
 #define RPH(NT_)                                                                                                          \
     do {                                                                                                                    \
         if (hot_partials) {                                                                                                 \
-            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_partials); \
-            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_partials); \
+            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_seg_cap, hot_partials); \
+            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID), dim3(64 * HotWaves<NT_>::value), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_seg_cap, hot_partials); \
         }                                                                                                                   \
-        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
-        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_seg_cap, (const float*)hot_partials); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID), dim3(TPB), 0, st, a, none, 0, hot_list, hot_count, hot_cap, hot_seg_cap, (const float*)hot_partials); \
     } while (0)
         if (chunks <= 1) RPH(1); else if (chunks <= 2) RPH(2); else if (chunks <= 3) RPH(3); else RPH(4);
 #undef RPH
@@ -1069,12 +1070,15 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
-int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap, uint32_t* hot_count,
-                           void* stp) {
+int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap, uint32_t seg_cap,
+                           uint32_t* hot_count, void* stp) {
     if (!col_start || ncols <= 0 || min_len < 1 || !hot_list || !hot_count || hot_cap == 0) return CLT_ERR_SHAPE;
     if (hipMemsetAsync(hot_count, 0, 2 * sizeof(uint32_t), as_stream(stp)) != hipSuccess) return CLT_ERR_LAUNCH;
+    // (a column that finds no room leaves a hole in the segment table: holes read as hot index -1)
+    if (seg_cap && hipMemsetAsync(hot_list + 2 * (size_t)hot_cap, 0xff, 2 * (size_t)seg_cap * sizeof(int32_t), as_stream(stp)) != hipSuccess)
+        return CLT_ERR_LAUNCH;
     hipLaunchKernelGGL(hot_columns_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, as_stream(stp), col_start, ncols, (uint32_t)min_len,
-                       hot_list, hot_cap, hot_count);
+                       hot_list, hot_cap, seg_cap, hot_count);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
@@ -1083,7 +1087,7 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
                                    const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
                                    double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
                                    int src_bf16, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
-                                   float* hot_partials, void* stp) {
+                                   uint32_t hot_seg_cap, float* hot_partials, void* stp) {
     if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
     if (nmat <= 0 || d <= 0 || F <= 0 || L <= 0 || step < 1 || !W || !m || !v || !rows || !src_layer || !src) return CLT_ERR_SHAPE;
     if (nmat > RP_GROUP_MAX) return 1;
@@ -1122,11 +1126,11 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
 #define RPGH(NT_)                                                                                              \
     do {                                                                                                        \
         if (hot_partials) {                                                                                     \
-            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_partials); \
-            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_partials); \
+            if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_seg_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_seg_cap, hot_partials); \
+            else hipLaunchKernelGGL((row_pass_seg_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(64 * HotWaves<NT_>::value), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_seg_cap, hot_partials); \
         }                                                                                                       \
-        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
-        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, (const float*)hot_partials); \
+        if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_hot_kernel<NT_, true>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_seg_cap, (const float*)hot_partials); \
+        else hipLaunchKernelGGL((row_pass_hot_kernel<NT_, false>), dim3(HOT_GRID / 4, nmat), dim3(TPB), 0, st, a, g, 1, hot_list, hot_count, hot_cap, hot_seg_cap, (const float*)hot_partials); \
     } while (0)
         if (chunks <= 1) RPGH(1); else if (chunks <= 2) RPGH(2); else if (chunks <= 3) RPGH(3); else RPGH(4);
 #undef RPGH

@@ -1325,13 +1325,15 @@ def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.
 #: columns (features) with more list entries than this are "hot": their weight rows go through the multi-wave launch of the row
 #: pass (clt_sparse_hot_columns / the hot_* arguments of clt_sparse_row_pass_f32).  0: off (A/B: CLT_AB=hot_min_len=0)
 HOT_MIN_LEN = ab_switch("hot_min_len", 64)
+#: segment slots of the hot-row scratch (64 entries each; 3.3 KB of partial sums a slot at d = 768: 105 MB per stream)
+HOT_SEG_SLOTS = 32768
 
 
 _HOT_SEEN = {}            # (device, B, L, F) -> [pinned int32 [1] with the last lists' hot-column count, event or None]
 
 
 def hot_columns(s: SparseLists):
-    """(hot block int32 [6 cap], counts int32 [2], cap, scratch by stream) of the lists' columns longer than HOT_MIN_LEN (the columns, their
+    """(hot block int32 [2 cap + 2 seg_cap], counts int32 [2], cap, scratch by stream, seg_cap) of the lists' columns longer than HOT_MIN_LEN (the columns, their
     segment slots and the segment table: include/clt_hip.h), computed once per lists object (one small kernel) and kept on it;
     None when switched off — or when the LAST lists of this shape on this device had no such column: the count is copied to
     pinned memory behind the kernel and read a step later (it has long arrived: no stall), and a workload without hot columns
@@ -1342,9 +1344,10 @@ def hot_columns(s: SparseLists):
     if hot is None and HOT_MIN_LEN > 0:
         dev = s.col_start.device
         cap = s.cap // (HOT_MIN_LEN + 1) + 1                 # more hot columns than this cannot exist
-        lst = torch.empty(6 * cap, dtype=torch.int32, device=dev)
+        seg_cap = min(2 * cap, HOT_SEG_SLOTS)                # (segments beyond it: those columns are walked whole, by one wave)
+        lst = torch.empty(2 * cap + 2 * seg_cap, dtype=torch.int32, device=dev)
         cnt = torch.empty(2, dtype=torch.int32, device=dev)
-        call("clt_sparse_hot_columns", s.col_start.data_ptr(), s.L * s.F, HOT_MIN_LEN, lst.data_ptr(), cap, cnt.data_ptr(), _stream())
+        call("clt_sparse_hot_columns", s.col_start.data_ptr(), s.L * s.F, HOT_MIN_LEN, lst.data_ptr(), cap, seg_cap, cnt.data_ptr(), _stream())
         seen = _HOT_SEEN.setdefault((dev.index, s.B, s.L, s.F), [torch.zeros(2, dtype=torch.int32).pin_memory(), None])
         enabled = True
         if seen[1] is not None:
@@ -1353,7 +1356,7 @@ def hot_columns(s: SparseLists):
         seen[0].copy_(cnt, non_blocking=True)
         seen[1] = torch.cuda.Event()
         seen[1].record()
-        hot = s.hot = (lst, cnt, cap, {}) if enabled else False
+        hot = s.hot = (lst, cnt, cap, {}, seg_cap) if enabled else False
     return hot or None
 
 
@@ -1362,15 +1365,15 @@ def _hot_args(s, d: int = 0, nmat: int = 1):
     different matrices may run on two streams at once — and grows to the largest (d, nmat) asked for."""
     hot = hot_columns(s)
     if hot is None:
-        return (None, None, 0, 0, None)
+        return (None, None, 0, 0, 0, None)
     part = None
     if 0 < d <= 1024 and d % 4 == 0:
-        need = nmat * 2 * hot[2] * (-(-d // 256) * 256 + 64)
+        need = nmat * hot[4] * (-(-d // 256) * 256 + 64)
         key = torch.cuda.current_stream().cuda_stream
         part = hot[3].get(key)
         if part is None or part.numel() < need:
             part = hot[3][key] = torch.empty(need, dtype=torch.float32, device=s.col_start.device)
-    return (hot[0].data_ptr(), hot[1].data_ptr(), hot[2], HOT_MIN_LEN, part.data_ptr() if part is not None else None)
+    return (hot[0].data_ptr(), hot[1].data_ptr(), hot[2], HOT_MIN_LEN, hot[4], part.data_ptr() if part is not None else None)
 
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,

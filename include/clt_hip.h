@@ -440,16 +440,16 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  * (their lists in equal segments, a block per segment; then a wave per row that adds the segment sums and updates the row) —
  * real dictionaries are heavy-tailed: a feature active in 10 % of the tokens is a 400-entry list.  Applies to d <= 1024
  * with 16-byte-aligned operands (ignored otherwise: one wave, or CW waves per long row, as before).
- * The hot block: hot_list is int32 [6 * hot_cap] — [0, cap) the hot columns, [cap, 2 cap) per hot column its first segment
- * slot (-1: the table was full, the column is walked whole), [2 cap, 6 cap) the segment table (2 cap pairs: hot index,
- * segment) — and hot_count uint32 [2] = {hot columns, segments}; hot_cap >= entries / (min_len + 1) + 1.  Every hot column
- * is cut into segments of 64 entries.  With hot_partials (scratch of 2 * hot_cap * (ceil(d / 256) * 256 + 64) floats — times
- * nmat for the group form; not to be shared by launches that may run concurrently) every segment is walked by a block of its
- * own and the row's wave adds the segments' sums in segment order: equal work items whatever the column lengths (a feature
- * that fires in half of the tokens — 2000 entries — no longer keeps one block busy while the chip waits).  Without
- * hot_partials a hot row is walked by one wave of the second launch. */
+ * The hot block: hot_list is int32 [2 * hot_cap + 2 * seg_cap] — [0, cap) the hot columns, [cap, 2 cap) per hot column its
+ * first segment slot (-1: the table was full, the column is walked whole by one wave), then the segment table (seg_cap pairs:
+ * hot index, segment) — and hot_count uint32 [2] = {hot columns, segments asked for}; hot_cap >= entries / (min_len + 1) + 1.
+ * Every hot column is cut into segments of 64 entries.  With hot_partials (scratch of seg_cap * (ceil(d / 256) * 256 + 64)
+ * floats — times nmat for the group form; not to be shared by launches that may run concurrently) every segment is walked by
+ * a block of its own and the row's wave adds the segments' sums in segment order: equal work items whatever the column
+ * lengths (a feature that fires in half of the tokens — 2000 entries — no longer keeps one block busy while the chip waits).
+ * Without hot_partials a hot row is walked by one wave of the second launch. */
 int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap,
-                           uint32_t* hot_count, void* stream);
+                           uint32_t seg_cap, uint32_t* hot_count, void* stream);
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
                             int L, int col0, int src_layer, const uint32_t* col_start, const int32_t* tok,
                             const float* coef, const float* src, const uint32_t* col_start2, const int32_t* tok2,
@@ -458,7 +458,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
                             const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
                             float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
-                            float* hot_partials, void* stream);
+                            uint32_t hot_seg_cap, float* hot_partials, void* stream);
 /* Several weight matrices of one decoder in ONE launch of the same pass (Adam in place; no gradient output, second list,
  * compact contribution or row term): matrix i has rows[i] rows of d floats (row r <-> CSC column r), gathers from src[i]
  * (a [B][L][d] tensor, layer src_layer[i]; fp32, or 16-bit when src_bf16) and writes its dots to slot
@@ -470,7 +470,7 @@ int clt_sparse_row_pass_group_f32(int nmat, float* const* W, float* const* m, fl
                                   const uint32_t* col_start, const int32_t* tok, const float* coef, float* dot_out, long dot_stride,
                                   double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, int step,
                                   int src_bf16, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
-                                  float* hot_partials, void* stream);
+                                  uint32_t hot_seg_cap, float* hot_partials, void* stream);
 
 /* Column compaction for the TopK-aux pass (clt_lightning.py:539-553: top k_aux among the DEAD features, second decoder
  * pass): the dead columns are gathered so that the pass runs as a dense sub-problem of n_pad columns per layer.
