@@ -3,7 +3,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; [ -n "$APPEND" ] || : > gpurun_out/configs.jsonl
-run() { echo "== $*" ; timeout -k 10 400 python -u bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | tee -a gpurun_out/configs.jsonl | cut -c1-420 || exit 1; }
+run() { sleep 4; echo "== $*" ; timeout -k 10 400 python -u bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | tee -a gpurun_out/configs.jsonl | cut -c1-420 || exit 1; }
 run --steps 20 --warmup 5
 run --steps 10 --warmup 3 --aux --nonlinearity topk
 run --steps 10 --warmup 3 --nonlinearity jumprelu --decoder plt
