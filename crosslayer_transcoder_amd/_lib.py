@@ -105,9 +105,10 @@ SIGNATURES = {
     "clt_sparse_reduce_dots_f32": (I, [P, L, P, I, I, I, P, P]),
     "clt_sparse_scatter_dense_f32": (I, [P, P, P, I, I, P, P]),
     "clt_adam_f32": (I, [P, P, P, P, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, I, P]),
+    "clt_adam_prep_f32": (I, [P, P, P, P, I, I, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, P, P, P]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class CltError(RuntimeError):

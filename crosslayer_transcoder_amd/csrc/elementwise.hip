@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WP_WAVES)))
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float4 v = vv[2 * i + e];
-                acc[2 * i + e] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                acc[2 * i + e] += sq4(v.x, v.y, v.z, v.w);       // (explicit FMAs: the same bits as row_sqnorm_kernel and adam_prep_kernel)
                 f[e][0] = v.x; f[e][1] = v.y; f[e][2] = v.z; f[e][3] = v.w;
             }
             if (op) store_rowpair16<F16>(op, row, n, col, tx, f[0], f[1], cin && row < rows, (n & 7) == 0);
@@ -959,7 +959,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         for (int u = 0; u < UN; ++u) {
             const long i = ((long)blockIdx.x * UN + u) * blockDim.x + threadIdx.x;
             if (i >= n4) break;
-            if (rdn) { const long row = i * 4 / rlen; const float cf = rdn[row] / sqrtf(rsq[row]); G[u].x += cf * P[u].x; G[u].y += cf * P[u].y; G[u].z += cf * P[u].z; G[u].w += cf * P[u].w; }
+            if (rdn) { const long row = i * 4 / rlen; const float cf = rdn[row] / sqrtf(rsq[row]); G[u].x = __fmaf_rn(cf, P[u].x, G[u].x); G[u].y = __fmaf_rn(cf, P[u].y, G[u].y); G[u].z = __fmaf_rn(cf, P[u].z, G[u].z); G[u].w = __fmaf_rn(cf, P[u].w, G[u].w); }
             upd(P[u].x, G[u].x, M[u].x, V[u].x); upd(P[u].y, G[u].y, M[u].y, V[u].y); upd(P[u].z, G[u].z, M[u].z, V[u].z); upd(P[u].w, G[u].w, M[u].w, V[u].w);
             ast(p, i, P[u]); ast(m, i, M[u]); ast(v, i, V[u]);
             if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack16<F16>(P[u].x, P[u].y), pack16<F16>(P[u].z, P[u].w));
@@ -968,10 +968,109 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
         float P = p[i], M = m[i], V = v[i];
         float G = g[i];
-        if (rdn) { const long row = i / rlen; G += rdn[row] / sqrtf(rsq[row]) * P; }
+        if (rdn) { const long row = i / rlen; G = __fmaf_rn(rdn[row] / sqrtf(rsq[row]), P, G); }
         upd(P, G, M, V);
         p[i] = P; m[i] = M; v[i] = V;
         if (sh) sh[i] = to16<F16>(P);
+    }
+}
+
+// Adam and the dense regime's weight preparation in ONE pass over a decoder matrix W [nb][rows][n] (round 3): every element is
+// updated as adam_kernel does (same FMA sequence, same row term, same loss-scaling rules) and the UPDATED values leave as the
+// fp32 weight, the 16-bit copy op, the transposed 16-bit copy opT [nb][n][rows] and the squared row norms sq[b * rows + r]
+// (overwritten, not accumulated) — what weight_prep_kernel would derive from the updated matrix at the next step, bit for
+// bit (same tiles, same summation order), without reading the 4 B/parameter again.  A skipped step (overflow flag) writes
+// nothing: op / opT / sq then still describe the unchanged weights.  grid (ceil(rows / 64), nb), rows % 8 == 0, n % 4 == 0.
+#ifndef APK_PAIRS
+#define APK_PAIRS 1
+#endif
+template <bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void adam_prep_kernel(float* __restrict__ W, const float* __restrict__ G,
+                                                                 float* __restrict__ M, float* __restrict__ V, int rows, int n,
+                                                                 uint16_t* __restrict__ op, uint16_t* __restrict__ opT, float* __restrict__ sq,
+                                                                 float lr, float omb1, float b2, float omb2, float eps, float wd, int adamw,
+                                                                 float step_size, float inv_sqrt_bc2, const float* __restrict__ rdn,
+                                                                 const float* __restrict__ rsq) {
+    if (clt_skip_update()) return;
+    const float unscale = clt_dev_state.grad_unscale;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= unscale;
+        if (wd != 0.0f) { if (adamw) pp *= (1.0f - lr * wd); else gg += wd * pp; }
+        mm = __fmaf_rn(gg - mm, omb1, mm);
+        vv = __fmaf_rn(vv, b2, (omb2 * gg) * gg);
+        const float denom = __fmaf_rn(sqrtf(vv), inv_sqrt_bc2, eps);
+        pp = __fmaf_rn(-step_size, mm / denom, pp);
+    };
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    auto ast = [](float* q, uint32_t idx, const float v[4]) { const nt_f4 t = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(q + idx)); };
+    __shared__ uint32_t tile[FT_R / 2][FT_PITCH];
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * FT_R;
+    const long boff = (long)blockIdx.y * rows * n;
+    W += boff; G += boff; M += boff; V += boff;
+    if (op) op += boff;
+    if (opT) opT += boff;
+    float acc[16], cf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc[i] = 0.0f;
+        const int row = r0 + 2 * (w + 4 * (i >> 1)) + (i & 1);
+        cf[i] = (rdn && row < rows) ? rdn[(long)blockIdx.y * rows + row] / sqrtf(rsq[(long)blockIdx.y * rows + row]) : 0.0f;
+    }
+    for (long c0 = 0; c0 < n; c0 += FT_C) {
+        const long col = c0 + 4 * tx;
+        const bool cin = col < n;
+#pragma unroll
+        for (int i0 = 0; i0 < 8; i0 += APK_PAIRS) {          // APK_PAIRS row pairs of the four streams in flight
+            float4 P[2 * APK_PAIRS], Gv[2 * APK_PAIRS], Mv[2 * APK_PAIRS], Vv[2 * APK_PAIRS];
+#pragma unroll
+            for (int u = 0; u < 2 * APK_PAIRS; ++u) {
+                // (one 32-bit element offset per row for all four streams: with 64-bit addresses per stream and row the
+                // loop-invariant address arithmetic alone took 128 registers and the kernel spilled)
+                const int row = r0 + 2 * (w + 4 * (i0 + (u >> 1))) + (u & 1);
+                const bool ok = cin && row < rows;
+                const uint32_t o = ok ? (uint32_t)row * (uint32_t)n + (uint32_t)col : 0u;
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                P[u] = *reinterpret_cast<const float4*>(W + o); Gv[u] = *reinterpret_cast<const float4*>(G + o);
+                Mv[u] = *reinterpret_cast<const float4*>(M + o); Vv[u] = *reinterpret_cast<const float4*>(V + o);
+                if (!ok) { P[u] = z; Gv[u] = z; Mv[u] = z; Vv[u] = z; }
+            }
+#pragma unroll
+            for (int q = 0; q < APK_PAIRS; ++q) {
+                const int i = i0 + q, pr = w + 4 * i, row = r0 + 2 * pr;
+                float f[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = 2 * q + e;
+                    float pv[4] = {P[u].x, P[u].y, P[u].z, P[u].w}, gv[4] = {Gv[u].x, Gv[u].y, Gv[u].z, Gv[u].w};
+                    float mv[4] = {Mv[u].x, Mv[u].y, Mv[u].z, Mv[u].w}, vv[4] = {Vv[u].x, Vv[u].y, Vv[u].z, Vv[u].w};
+                    const float c = cf[2 * i + e];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { if (rdn) gv[k] = __fmaf_rn(c, pv[k], gv[k]); upd(pv[k], gv[k], mv[k], vv[k]); f[e][k] = pv[k]; }
+                    if (cin && row + e < rows) {
+                        const uint32_t o = (uint32_t)(row + e) * (uint32_t)n + (uint32_t)col;
+                        ast(W, o, pv); ast(M, o, mv); ast(V, o, vv);
+                    }
+                    acc[2 * i + e] += sq4(pv[0], pv[1], pv[2], pv[3]);
+                }
+                if (op) store_rowpair16<F16>(op, row, n, col, tx, f[0], f[1], cin && row < rows, (n & 7) == 0);
+                ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
+            }
+            asm volatile("" ::: "memory");                   // (the next rows' loads stay behind these rows' stores)
+        }
+        if (opT) {
+            __syncthreads();
+            ft_write_transposed(tile, opT, c0, r0, rows, n);
+            __syncthreads();
+        }
+    }
+    if (sq) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float s = wave_sum(acc[i]);
+            const int row = r0 + 2 * (w + 4 * (i >> 1)) + (i & 1);
+            if (tx == 0 && row < rows) sq[(long)blockIdx.y * rows + row] = s;
+        }
     }
 }
 }  // namespace
@@ -982,7 +1081,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 13; }
+int clt_abi_version(void) { return 14; }
 
 int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
     if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;
@@ -1347,6 +1446,23 @@ int clt_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr
                        (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow, row_dnorm, row_sq, row_len);
     else hipLaunchKernelGGL((adam_kernel<false>), dim3(adam_blocks), dim3(TPB), 0, as_stream(st), p, g, m, v, n4, n,
                        (float)lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, shadow, row_dnorm, row_sq, row_len);
+    CLT_LAUNCH_CHECK(); return CLT_OK;
+}
+
+int clt_adam_prep_f32(float* p, const float* g, float* m, float* v, int nb, int rows, int n, double lr, double b1, double b2, double eps,
+                      double wd, int adamw, int step, uint16_t* op, uint16_t* opT, float* sq, const float* row_dnorm,
+                      const float* row_sq, void* st) {
+    if (nb <= 0 || rows <= 0 || n <= 0 || step < 1 || !p || !g || !m || !v) return CLT_ERR_SHAPE;
+    if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
+    if (rows % 8 || n % 4 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (op && !aligned16(op)) || (opT && !aligned16(opT)))
+        return CLT_ERR_ALIGN;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const float step_size = (float)(lr / bc1), isb2 = (float)(1.0 / sqrt(bc2));
+    const dim3 grid((rows + FT_R - 1) / FT_R, nb);
+    if (clt_host_state.fp16) hipLaunchKernelGGL((adam_prep_kernel<true>), grid, dim3(256), 0, as_stream(st), p, g, m, v, rows, n, op, opT, sq, (float)lr,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, row_dnorm, row_sq);
+    else hipLaunchKernelGGL((adam_prep_kernel<false>), grid, dim3(256), 0, as_stream(st), p, g, m, v, rows, n, op, opT, sq, (float)lr,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, adamw, step_size, isb2, row_dnorm, row_sq);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 }  // extern "C"

@@ -118,6 +118,9 @@ LIST_BF16_ACTIVATIONS = bool(ab_switch("list_bf16_act", 1))
 FUSE_DENSE_JUMPRELU = True
 #: dense bf16 regime: bf16 copy + transposed bf16 copy + squared row norms of each decoder matrix in one pass over it
 FUSE_WEIGHT_PREP = True
+#: ... and that pass folded into the optimizer's update of the matrix (clt_adam_prep_f32: the updated values leave in all four
+#: forms, the next step reads no fp32 weight for its operands); likewise the encoder's 16-bit shadow (CLT_AB=fuse_adam_prep=0: off)
+FUSE_ADAM_PREP = bool(ab_switch("fuse_adam_prep", 1))
 #: list regime, bf16 mode, base loss: loss sum + bf16 gradient rows + decoder bias gradient in one pass over the error
 FUSE_MSE_BF16 = True
 #: feature-sharded list regime, cross-layer decoder, base loss: the partial reconstruction is written layer-major and
@@ -150,8 +153,13 @@ def _encoder_operand(enc):
     sh = getattr(enc, "_bf16_shadow", None)
     ver = (enc.W._version, getattr(enc.W, "_clt_version", 0), Wt.data_ptr(), ops.op16())
     if sh is None or enc._shadow_version != ver:
-        sh = ops.cast_bf16(Wt)
-        enc._bf16_shadow, enc._shadow_version = sh, ver
+        tagged = getattr(enc.W, "_clt_shadow", None)          # written by the optimizer's own update pass (optim.add_shadow)
+        if (FUSE_ADAM_PREP and sh is not None and tagged is not None and tagged[1] is sh
+                and tagged[0] == (enc.W._version, getattr(enc.W, "_clt_version", 0), ops.op16())):
+            enc._shadow_version = ver
+        else:
+            sh = ops.cast_bf16(Wt)
+            enc._bf16_shadow, enc._shadow_version = sh, ver
     return sh
 
 
@@ -191,6 +199,15 @@ class _Decoder:
             return
         F = self.dec.d_features
         sq = torch.zeros(self.L * F, dtype=torch.float32, device=self.W32[0].device)
+        if FUSE_ADAM_PREP:
+            # the optimizer's update pass of the last step left all three forms of every UPDATED matrix behind (optim.add_prep,
+            # clt_adam_prep_f32): same bits as the preparation pass below would produce, no read of the fp32 weights
+            tags = [getattr(w, "_clt_prep", None) for w in self.W32]
+            if all(t is not None and t[0] == (w._version, getattr(w, "_clt_version", 0), ops.op16()) for t, w in zip(tags, self.W32)):
+                for t in tags:                  # ascending l: the reference's accumulation order (:440-444)
+                    sq[:t[3].numel()] += t[3]
+                self._Wop, self._WT, self._sq = [t[1] for t in tags], [t[2] for t in tags], sq
+                return
         Wop, WT = [], []
         for w in self.W32:                      # ascending l: the reference's accumulation order (:440-444)
             r = ops.weight_prep_bf16(w, sq, True) if w.is_contiguous() else None
@@ -198,6 +215,19 @@ class _Decoder:
                 return
             Wop.append(r[0]); WT.append(r[1])
         self._Wop, self._WT, self._sq = Wop, WT, sq
+
+    def register_prep(self, optimizer, enc=None):
+        """Dense 16-bit regime with a FusedAdam: the coming optimizer.step() refreshes this step's operand buffers in its own
+        pass over each decoder matrix (and the encoder's 16-bit shadow), so the next step's _prep / _encoder_operand read no
+        fp32 weights."""
+        if not (FUSE_ADAM_PREP and self.bf16 and hasattr(optimizer, "add_prep")):
+            return
+        if self._Wop is not None and self._WT is not None and not self.shadow:
+            for w, op, opT in zip(self.W32, self._Wop, self._WT):
+                if w.is_contiguous() and w.dim() == 3:
+                    optimizer.add_prep(w, op, opT, torch.empty(w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device))
+        if enc is not None and getattr(enc, "_bf16_shadow", None) is not None:
+            optimizer.add_shadow(enc.W, enc._bf16_shadow)
 
     @property
     def Wop(self):
@@ -1007,6 +1037,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     else:
         grads["encoder.W"] = ops.encoder_wgrad(xo, dpre).permute(0, 2, 1)
     grads["encoder.b"] = db if dpreT is not None else ops.column_sum(dpre)
+    if optimizer is not None:
+        D.register_prep(optimizer, enc)
     terms["loss"] = loss
     out["loss"] = loss
     return out

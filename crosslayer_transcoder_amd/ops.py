@@ -845,6 +845,32 @@ def adam(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wei
          p.shape[-1] if row_term is not None else 0, _stream())
 
 
+def adam_prep(p, g, m, v, step: int, lr: float, beta1, beta2, eps, weight_decay, adamw, op, opT, sq_part, row_term=None) -> bool:
+    """clt_adam_prep_f32: the Adam step of a contiguous decoder matrix p [nb, rows, n] that also leaves the updated matrix's
+    16-bit copy (op, same shape), transposed 16-bit copy (opT [nb, n, rows]) and squared row norms (sq_part [nb * rows]) — the
+    next step's weight preparation.  False when the layout does not qualify (the caller then runs ops.adam)."""
+    if p.dim() != 3 or not all(t.is_contiguous() and t.shape == p.shape for t in (p, g, m, v)):
+        return False
+    nb, rows, n = p.shape
+    if rows % 8 or n % 4 or op.dtype != op16() or opT.dtype != op16() or op.shape != p.shape or opT.shape != (nb, n, rows):
+        return False
+    for t in (p, g, m, v, sq_part):
+        _chk(t)
+    assert sq_part.numel() >= nb * rows
+    if row_term is not None:
+        _chk(row_term[0]); _chk(row_term[1])
+        assert row_term[0].numel() >= nb * rows
+    rc = lib.clt_adam_prep_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), nb, rows, n, float(lr), float(beta1), float(beta2),
+                               float(eps), float(weight_decay), int(adamw), int(step), _chk(op, op16()).data_ptr(), _chk(opT, op16()).data_ptr(),
+                               sq_part.data_ptr(), row_term[0].data_ptr() if row_term is not None else None,
+                               row_term[1].data_ptr() if row_term is not None else None, _stream())
+    if rc == -4:                                  # CLT_ERR_ALIGN
+        return False
+    if rc != 0:
+        raise CltError("clt_adam_prep_f32", rc)
+    return True
+
+
 # ------------------------------------------------------------------------------ sparse decoder path
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""

@@ -21,6 +21,10 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adamw=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
         self._row_terms = {}
+        #: dense 16-bit regime (engine._Decoder.register_prep / engine._encoder_operand): buffers the update kernel refreshes in
+        #: the same pass — id(p) -> (op, opT, sq_part) of a decoder matrix, id(p) -> 16-bit shadow of the encoder weight
+        self._preps = {}
+        self._shadows = {}
         #: fp16 loss scaling only (set by the training step): remember the parameters whose step count moved, so that
         #: commit(skipped=True) can give the counts back after a step the kernels skipped
         self.track_steps = False
@@ -31,6 +35,15 @@ class FusedAdam(torch.optim.Optimizer):
         gradient that reaches the decoder weights through dec_norms, clt_lightning.py:438-446) — instead of a
         separate read-modify-write pass over the gradient."""
         self._row_terms[id(p)] = (dnorm, sq)
+
+    def add_prep(self, p, op, opT, sq_part):
+        """The next step() of the contiguous decoder matrix p also writes the updated matrix's 16-bit copy, transposed 16-bit
+        copy and squared row norms into these buffers (clt_adam_prep_f32) and tags p with them (`p._clt_prep`)."""
+        self._preps[id(p)] = (op, opT, sq_part)
+
+    def add_shadow(self, p, shadow):
+        """The next step() of p also writes the updated values' 16-bit copy (raw memory order of p) into `shadow`."""
+        self._shadows[id(p)] = shadow
 
     def _state(self, p):
         st = self.state[p]
@@ -65,6 +78,11 @@ class FusedAdam(torch.optim.Optimizer):
         if skipped:
             for p in self._stepped:
                 self.state[p]["step"] -= 1
+                # (the skipped kernels wrote nothing: buffers registered for this step — a fresh squared-norm buffer among them —
+                # do not describe the weights; the next step prepares its operands from the fp32 weights again)
+                for tag in ("_clt_prep", "_clt_shadow"):
+                    if hasattr(p, tag):
+                        delattr(p, tag)
         self._stepped = []
 
     @torch.no_grad()
@@ -83,7 +101,20 @@ class FusedAdam(torch.optim.Optimizer):
                 if self.track_steps:
                     self._stepped.append(p)
                 g = _same_layout(p.grad, p)
-                ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
-                         group["weight_decay"], group["adamw"], None, self._row_terms.pop(id(p), None))
-                p._clt_version = getattr(p, "_clt_version", 0) + 1      # cached bf16 operand copies re-cast
+                row_term = self._row_terms.pop(id(p), None)
+                prep = self._preps.pop(id(p), None)
+                shadow = self._shadows.pop(id(p), None)
+                done = prep is not None and ops.adam_prep(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2,
+                                                          group["eps"], group["weight_decay"], group["adamw"], *prep, row_term=row_term)
+                if not done:
+                    ops.adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], b1, b2, group["eps"],
+                             group["weight_decay"], group["adamw"], shadow, row_term)
+                p._clt_version = getattr(p, "_clt_version", 0) + 1      # cached 16-bit operand copies: re-cast, unless tagged below
+                key = (p._version, p._clt_version, ops.op16())
+                if done:
+                    p._clt_prep = (key,) + tuple(prep)
+                elif shadow is not None:
+                    p._clt_shadow = (key, shadow)
+        self._preps.clear()                     # (registrations are for ONE step: nothing stale survives a parameter without gradient)
+        self._shadows.clear()
         return loss

@@ -256,6 +256,15 @@ int clt_operand_format(void);     /* 0 bf16, 1 fp16 */
 int clt_adam_f32(float* p, const float* g, float* m, float* v, long count, double lr, double beta1,
                  double beta2, double eps, double weight_decay, int adamw, int step, uint16_t* bf16_shadow,
                  const float* row_dnorm, const float* row_sq, int row_len, void* stream);
+/* clt_adam_f32 and clt_weight_prep_bf16 in one pass over a decoder matrix p [nb][rows][n] of the dense 16-bit regime (no
+ * counterpart in the reference: there torch.optim.Adam steps and the next forward's autocast casts / bmm transposes / W**2
+ * read the weights again): the updated values leave as fp32 p, as the 16-bit copy op, the transposed 16-bit copy opT
+ * [nb][n][rows] and the squared row norms sq[b * rows + r] (overwritten) — bit for bit what clt_weight_prep_bf16 derives from
+ * the updated matrix.  row_dnorm / row_sq: the row term of clt_adam_f32, indexed b * rows + r.  A step skipped under loss
+ * scaling writes nothing.  rows % 8 == 0, n % 4 == 0, 16-byte aligned (CLT_ERR_ALIGN otherwise). */
+int clt_adam_prep_f32(float* p, const float* g, float* m, float* v, int nb, int rows, int n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int adamw, int step, uint16_t* op, uint16_t* opT, float* sq,
+                      const float* row_dnorm, const float* row_sq, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sparse decoder path (K5b/K6 sparse, fused with K13) — replaces the dense bmm's of clt.py:334-343 and

@@ -30,3 +30,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _library_state_does_not_leak(request):
+    """The 16-bit operand format and the loss scale are process-wide library state (clt_set_loss_scaling): a GPU test that ran
+    fp16 steps leaves it set, and the next test's kernels (an Adam that unscales by 1 / 65536) would inherit it.  Back to the
+    default precision and the default state after every GPU test."""
+    yield
+    if "gpu" in request.keywords and torch.cuda.is_available():
+        import crosslayer_transcoder_amd as cta
+        from crosslayer_transcoder_amd import ops
+        cta.set_precision("32")
+        ops.set_loss_scaling(False)

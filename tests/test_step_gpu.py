@@ -355,6 +355,52 @@ def test_fused_encoder_rows_select_equals_unfused():
         assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the unfused path"
 
 
+@pytest.mark.parametrize("prec", ["bf16-mixed", "16-mixed"])
+@pytest.mark.parametrize("dec_kind", ["clt", "plt"])
+def test_adam_pass_that_also_prepares_the_next_steps_operands(dec_kind, prec):
+    """Dense 16-bit regime: the optimizer's update of a decoder matrix also writes the updated matrix's 16-bit copy, transposed
+    copy and squared row norms (clt_adam_prep_f32), and the encoder's update its 16-bit shadow — the next step then reads no
+    fp32 weight for its operands.  Same bits as preparing them from the updated weights: four training steps (fp16: the first
+    ones are skipped by the loss scaler, whose registrations must not leak) equal the unfused path exactly."""
+    import crosslayer_transcoder_amd.engine as E
+    from crosslayer_transcoder_amd import precision
+    from tests.build_cases import build_module
+    B, L, d, F = 256, 3, 128, 512
+    g = torch.Generator().manual_seed(31)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(4)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d), "nonlinearity.theta": torch.full((1, L, F), 0.03)}
+    if dec_kind == "clt":
+        for l in range(L):
+            params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    else:
+        params["decoder.W"] = (torch.rand(L, F, d, generator=g) * 2 - 1) * d ** -0.5
+    cfg = {"decoder": dec_kind, "d_features": F, "nonlinearity": {"kind": "jumprelu", "theta": 0.03, "bandwidth": 1.0},
+           "loss": {"kind": "jumprelu", "lambda_sparsity": 2e-4, "c_sparsity": 0.1, "use_tanh": True, "pre_actv_loss": 1e-8}}
+    case = {"cfg": cfg, "opt": {"lr": 1e-3}, "batches": torch.stack(batches), "init_params": params,
+            "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+    results = {}
+    for fuse in (True, False):
+        E.FUSE_ADAM_PREP = fuse
+        try:
+            mod = build_module(case)
+            mod.global_step = 5
+            mod.log_metrics_every = 0
+            opt = mod.configure_optimizers()
+            losses, tagged = [], 0
+            with precision(prec):
+                for t, b in enumerate(batches):
+                    losses.append(float(mod.fused_train_step(b.cuda(), t, opt, sparse=False)))
+                    tagged += all(hasattr(w, "_clt_prep") for w in mod.model.decoder.weights())
+            results[fuse] = (losses, {k: p.detach().clone() for k, p in mod.model.named_parameters()}, tagged)
+        finally:
+            E.FUSE_ADAM_PREP = True
+    assert results[True][2] >= 2 and results[False][2] == 0, (results[True][2], results[False][2])
+    assert results[True][0] == results[False][0], (results[True][0], results[False][0])
+    for k, p in results[True][1].items():
+        assert torch.equal(p, results[False][1][k]), f"{k} differs between the fused and the separate preparation"
+
+
 def test_pinned_prefetcher_and_fit_loop(golden):
     """Batch ingest edge: double-buffered pinned H2D yields exactly the host batches (pinned and pageable sources, fp16
     and fp32), and trainer.fit on the debug-cpu golden reproduces the reference loss curve through it."""
