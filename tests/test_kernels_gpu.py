@@ -710,13 +710,23 @@ def test_mse_bf16_colsum_one_pass(ops, B, L, d):
     assert torch.allclose(colsum, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("slab,bf16", [(False, False), (True, True), (False, True)])
-def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16):
+@pytest.mark.parametrize("slab,bf16,hot", [(False, False, False), (True, True, False), (False, True, False), (False, True, True),
+                                          (True, False, True)])
+def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16, hot):
     """clt_sparse_row_pass_group_f32 (all matrices of a cross-layer decoder in one launch) against one
-    clt_sparse_row_pass_f32 launch per matrix: same arithmetic per row, so weights, moments, shadows and dots are bit-identical."""
-    B, L, F, d = 37, 4, 96, 40
+    clt_sparse_row_pass_f32 launch per matrix: same arithmetic per row, so weights, moments, shadows and dots are bit-identical.
+    hot: three features of every layer fire in every token (columns of 300 entries: walked in segments by the hot-row
+    launches of both forms, the group form with a scratch region per matrix); both forms also agree with the one-wave-per-row
+    form to summation-order rounding."""
+    B, L, F, d = (300, 4, 96, 40) if hot else (37, 4, 96, 40)
     feat = _sparse_features(B, L, F, 6, seed=3)
-    S = ops.sparse_build(feat.to(DEV), 6 * B * L)
+    if hot:
+        feat[:, :, 10:13] = torch.rand(B, L, 3, generator=torch.Generator().manual_seed(2)) + 0.5
+    S = ops.sparse_build(feat.to(DEV), int((feat > 0).sum()))
+    if hot:
+        assert ops.hot_columns(S) is not None
+        lens = (S.col_start[1:] - S.col_start[:-1])
+        assert int(lens.max()) == B and int((lens > ops.HOT_MIN_LEN).sum()) == 3 * L
     g = _rand(B, L, d, seed=5).to(DEV)
     src = ops.cast_bf16(g) if bf16 else g
     g_lm = src.permute(1, 0, 2).contiguous()                     # layer-major slabs [L, B, d]
@@ -743,6 +753,23 @@ def test_sparse_row_pass_group_equals_per_matrix_launches(ops, slab, bf16):
             assert torch.equal(x, y)
     assert torch.equal(res[0][4], res[1][4])
     assert not torch.equal(res[0][0][L - 1], _rand(L, F, d, seed=20 + L - 1, scale=0.05).to(DEV))     # (the pass did move the weights)
+    if hot:                                              # the same passes with one wave per row, whatever its length
+        hot0 = ops.HOT_MIN_LEN
+        try:
+            ops.HOT_MIN_LEN = 0
+            S1 = ops.sparse_build(feat.to(DEV), int((feat > 0).sum()))
+            Ws = [_rand(l + 1, F, d, seed=20 + l, scale=0.05).to(DEV) for l in range(L)]
+            ms = [_rand(l + 1, F, d, seed=30 + l, scale=0.01).to(DEV) for l in range(L)]
+            vs = [_rand(l + 1, F, d, seed=40 + l, scale=0.01).to(DEV).abs() for l in range(L)]
+            dots1 = torch.zeros(L, S1.cap, device=DEV)
+            for l in range(L - 1, -1, -1):
+                ops.sparse_row_pass(Ws[l], S1, S1.csc_val, g_lm[l] if slab else src, 0, l, adam=hp, m=ms[l], v=vs[l], dots=dots1,
+                                    dot_slot=-1, src_slab=slab)
+        finally:
+            ops.HOT_MIN_LEN = hot0
+        assert torch.equal(dots1, res[0][4])             # (a dot is one entry's: no summation order involved)
+        for l in range(L):
+            assert_close(res[0][1][l], ms[l], 1e-4, 1e-6 * float(ms[l].abs().max()), what=f"exp_avg of W_{l}, hot rows vs one wave per row")
 
 
 @pytest.mark.parametrize("d,bf16", [(40, True), (768, True), (70, False), (1024, False)])
