@@ -128,6 +128,9 @@ FUSE_MSE_BF16 = True
 #: (which gathers only g[:, l, :]) start as soon as slab l has arrived, so the exchange of the other layers runs under
 #: them instead of in front of the whole backward pass
 PIPELINE_EXCHANGE = True
+#: ... in its reduce-scatter (fp32 partial sums) + all-gather (16-bit gradient rows) form, the loss pass on 1/world of the
+#: tokens per rank (CLT_AB=exchange_split=0: one fp32 all-reduce per layer group, every rank computes the whole loss)
+EXCHANGE_SPLIT = bool(ab_switch("exchange_split", 1))
 #: thresholding sparsifiers (JumpReLU / ReLU): break-even between the activation-list regime and the dense GEMM regime as
 #: a share of the B*L*F entries that are active (L0 / F).  Below it the decoder forward is a row gather and the decoder
 #: weight gradient + Adam one fused row pass; above it (e.g. an untrained JumpReLU at theta = 0.03: ~45 % active) the
@@ -498,16 +501,91 @@ def _threshold_lists(mod, pre, theta, force: bool, bias=None):
     return S
 
 
-def _forward_and_exchange(D, S, shard, d):
+class _SplitExchange:
+    """State of the split exchange of one step (see _forward_and_exchange): this rank's token block of the reduced
+    reconstruction, the gathered gradient slabs, and the two small sums that are complete only after finish()."""
+
+    def __init__(self, shard, L, Bn, d, g_dtype, dev):
+        self.shard, self.Bc = shard, Bn // shard.world
+        self.r_part = torch.empty(L, self.Bc, d, dtype=torch.float32, device=dev)
+        self.g_part = torch.empty(L, self.Bc, d, dtype=g_dtype, device=dev)
+        self.g_lm = torch.empty(L, Bn, d, dtype=g_dtype, device=dev)
+        self.b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
+        self.loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
+        self._late = []
+
+    def tensors(self):
+        return (self.r_part, self.g_part, self.g_lm, self.b_grad, self.loss_parts)
+
+    def finish(self):
+        """The current stream waits for the sums over ranks of the bias-gradient rows and the loss partials."""
+        for w in self._late:
+            w()
+        self._late = []
+
+    def recons_norm(self):
+        """The reduced reconstruction [B, L, d], gathered from the ranks' token blocks.  A collective: every rank has to ask
+        for it in the same step (the training metrics do; the step itself never needs it)."""
+        L, Bc, d = self.r_part.shape
+        full = torch.empty(L, Bc * self.shard.world, d, dtype=torch.float32, device=self.r_part.device)
+        self.shard.all_gather_rows_async([full[l] for l in range(L)], [self.r_part[l] for l in range(L)])()
+        return full.permute(1, 0, 2).contiguous()
+
+
+_loss_streams = {}
+
+
+def _loss_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _loss_streams:
+        _loss_streams[key] = torch.cuda.Stream(device=dev)
+    return _loss_streams[key]
+
+
+def _forward_and_exchange(D, S, shard, d, split=None):
     """Pipelined exchange, forward half: the partial reconstruction layer-major [L, B, d], gathered layer group by layer
-    group (last layers first); each group's all-reduce is queued on RCCL's stream as soon as its slabs are written, so it
-    runs under the gather of the next group (and later under the weight passes).  Returns (r_lm, [wait per group])."""
+    group (last layers first).  Returns (r_lm, [wait per group], split state or None).
+
+    split is None: each group's all-reduce is queued on RCCL's stream as soon as its slabs are written, so it runs under the
+    gather of the next group (and later under the weight passes); the caller computes the group's loss after its wait.
+
+    split = (mlp_out, output standardizer, N, 16-bit?): reduce-scatter + all-gather form.  The group's fp32 slabs are
+    reduce-scattered over token blocks (rank r receives tokens [r*B/world, (r+1)*B/world) of every layer of the group), the
+    loss kernel runs on that block alone — on a stream of its own, so that it waits for nobody but its reduce-scatter — and
+    the gradient rows it writes (16-bit in the 16-bit modes: the form the weight passes gather) are all-gathered.  Per rank
+    (world-1)/world * (4 + 2) bytes per element cross the links instead of the all-reduce's 8, and the loss pass reads
+    1/world of the rows.  The whole chain of a group is queued here, in front of the weight passes: wait i is the all-gather's."""
     r_lm, waits = None, []
-    for lo, hi in _exchange_groups(D.L):
+    if split is None:
+        for lo, hi in _exchange_groups(D.L):
+            r_lm = ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True, w_bf16=D.shadow, layer_major=True, out=r_lm,
+                                          layers=(lo, hi))
+            waits.append(shard.all_reduce_sum_async(r_lm[lo:hi]))
+        return r_lm, waits, None
+    mlp_out, ost, N, bf16 = split
+    Bn, dev = mlp_out.shape[0], mlp_out.device
+    ex = _SplitExchange(shard, D.L, Bn, d, ops.op16() if bf16 else torch.float32, dev)
+    side = _loss_stream(dev)
+    for t in ex.tensors():
+        t.record_stream(side)                    # (written on the loss stream; a void attempt drops them without waiting)
+    y = mlp_out[shard.rank * ex.Bc:(shard.rank + 1) * ex.Bc]
+    for gi, (lo, hi) in enumerate(_exchange_groups(D.L)):
         r_lm = ops.sparse_decoder_fwd(S, D.pointer_table(), D._bias(), d, True, w_bf16=D.shadow, layer_major=True, out=r_lm,
                                       layers=(lo, hi))
-        waits.append(shard.all_reduce_sum_async(r_lm[lo:hi]))
-    return r_lm, waits
+        scattered = shard.reduce_scatter_rows_async([ex.r_part[l] for l in range(lo, hi)], [r_lm[l] for l in range(lo, hi)])
+        with torch.cuda.stream(side):
+            scattered()
+            if not (bf16 and ops.mse_bf16_colsum_layers(ex.r_part[lo:hi], y[:, lo:hi], ost.mean[lo:hi], ost.std[lo:hi], N,
+                                                        ex.g_part[lo:hi], ex.b_grad[lo:hi], ex.loss_parts[gi:gi + 1])):
+                for ll in range(lo, hi):         # generic form, layer by layer (fp32 mode, odd shapes)
+                    ls, gl, _ = ops.mse(ex.r_part[ll], y[:, ll], ost.mean[ll], ost.std[ll], True, False, count=N)
+                    ex.loss_parts[gi:gi + 1].add_(ls)
+                    ops.column_sum(gl, ex.b_grad[ll])
+                    ex.g_part[ll].copy_(ops.cast_bf16(gl) if bf16 else gl)
+            waits.append(shard.all_gather_rows_async([ex.g_lm[l] for l in range(lo, hi)], [ex.g_part[l] for l in range(lo, hi)]))
+    with torch.cuda.stream(side):                # the two small sums, behind the last group's gather on RCCL's stream
+        ex._late = [shard.all_reduce_sum_async(ex.b_grad), shard.all_reduce_sum_async(ex.loss_parts)]
+    return r_lm, waits, ex
 
 
 def _exchange_groups(L):
@@ -626,6 +704,9 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     theta = None
     feat = S = pre = fused_ops = dpreT = None
     batch_mode = isinstance(nl, (BatchTopK, PerLayerBatchTopK))
+    # pipelined exchange in its reduce-scatter + all-gather form (every rank decides from the shapes alone)
+    split_args = ((mlp_out, ost, Bn * L * d, bf16) if (EXCHANGE_SPLIT and shard is not None and Bn % shard.world == 0
+                                                      and (shard.world > 1 or shard.keep_single)) else None)
     pending = None                               # deferred host read of the fused selection's outcome (see _settle_select)
     probe = getattr(nl, "_kth_probe", None)
     if probe is not None and probe.value():
@@ -647,8 +728,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             D_ = _Decoder(dec, shard, shadow=optimizer is not None)
             lm = bool(PIPELINE_EXCHANGE and shard is not None and D_.clt and not fp16)
             if lm:
-                return (D_, True) + _forward_and_exchange(D_, S_, shard, d)
-            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None
+                return (D_, True) + _forward_and_exchange(D_, S_, shard, d, split_args)
+            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
 
         S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
                                           nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
@@ -686,7 +767,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         # of the features, candidates filed per row by the full GEMM's epilogue, exact selection on those
         def _spec_rows(S_):
             D_ = _Decoder(dec, None, shadow=optimizer is not None)
-            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None
+            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
 
         S = ops.encoder_select_rows_lists(xo, _encoder_operand(enc), enc.b, nl.k, offset=batch_idx,
                                           speculate=_spec_rows if SPECULATIVE_FORWARD else None)
@@ -786,7 +867,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         # and the launch queue is empty); the dead-feature update and its tiny all-reduce follow, and only then are the
         # all-reduces of the layer groups queued on RCCL's stream — no small collective waits behind them
         groups = _exchange_groups(L)                       # [(lo, hi)], last layers first
-        r_lm, waits = (spec[2], spec[3]) if spec is not None and spec[1] else _forward_and_exchange(D, S, shard, d)
+        r_lm, waits, ex = (spec[2], spec[3], spec[4]) if spec is not None and spec[1] else _forward_and_exchange(D, S, shard, d,
+                                                                                                                  split_args)
         if pending is None:
             dead, dead_cnt = dead_features()
         r = None
@@ -806,9 +888,12 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         # per layer, once its slab has been reduced: loss partial + gradient slab (+ bias-gradient row); called by the
         # backward pass right before the weight pass of W_l
         g = ys = None
-        loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
-        b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
-        g_lm = torch.empty(L, Bn, d, dtype=ops.op16() if bf16 else torch.float32, device=dev)
+        if ex is not None:                               # split form: the loss ran on this rank's token block, per group
+            loss_parts, b_grad, g_lm = ex.loss_parts, ex.b_grad, ex.g_lm
+        else:
+            loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
+            b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
+            g_lm = torch.empty(L, Bn, d, dtype=ops.op16() if bf16 else torch.float32, device=dev)
 
         group_of = {l: gi for gi, (lo, hi) in enumerate(groups) for l in range(lo, hi)}
         done = set()
@@ -818,6 +903,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             if gi not in done:                           # first layer of its group: wait for the group's all-reduce, then its loss
                 done.add(gi)
                 waits[gi]()                              # (the current stream waits; the host does not)
+                if ex is not None:                       # (... for the group's gathered gradient slabs: nothing left to compute)
+                    return g_lm[l]
                 lo, hi = groups[gi]
                 if not (bf16 and ops.mse_bf16_colsum_layers(r_lm[lo:hi], mlp_out[:, lo:hi], ost.mean[lo:hi], ost.std[lo:hi], N,
                                                             g_lm[lo:hi], b_grad[lo:hi], loss_parts[gi:gi + 1])):
@@ -849,7 +936,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     out["grad_scale"] = ops.GRAD_SCALE           # out["grads"] carry this factor (1.0 outside fp16 mode)
     out.lazy = {}
     if pipelined:
-        out.lazy["recons_norm"] = lambda: r_lm.permute(1, 0, 2).contiguous()
+        out.lazy["recons_norm"] = ex.recons_norm if ex is not None else (lambda: r_lm.permute(1, 0, 2).contiguous())
     else:
         out["recons_norm"] = r
     if pre is not None and not act16:
@@ -944,6 +1031,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
                                    slabs=slabs, groups=groups if pipelined else None)
         if pipelined:
+            if ex is not None:
+                ex.finish()
             terms["mse"] = (loss_parts.sum() / N).float()
             loss = terms["mse"]
             late_dead[1]()

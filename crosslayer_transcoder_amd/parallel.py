@@ -59,6 +59,37 @@ class FeatureShard:
         work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return work.wait
 
+    def reduce_scatter_rows_async(self, outs, ins):
+        """For every pair: outs[i] [rows / world, d] <- block `rank` of the sum over ranks of ins[i] [rows, d].  All pairs go
+        out as ONE coalesced RCCL launch on RCCL's stream, behind the work already queued on the current stream; the returned
+        wait() makes the stream that is current WHEN IT IS CALLED wait for it.  Host-staged (gloo) groups: all-reduce on the
+        host, own block kept, at once."""
+        if self._host_staged:
+            for o, i in zip(outs, ins):
+                h = i.cpu() if i.is_cuda else i.clone()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                n = o.shape[0]
+                o.copy_(h[self.rank * n:(self.rank + 1) * n])
+            return lambda: None
+        with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+            for o, i in zip(outs, ins):
+                dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM, group=self.group)
+        return cm.wait
+
+    def all_gather_rows_async(self, outs, ins):
+        """For every pair: outs[i] [rows, d] <- the ranks' ins[i] [rows / world, d] in rank order; one coalesced launch, wait()
+        as in reduce_scatter_rows_async."""
+        if self._host_staged:
+            for o, i in zip(outs, ins):
+                h = torch.empty(o.shape, dtype=o.dtype)
+                dist.all_gather_into_tensor(h, i.cpu() if i.is_cuda else i, group=self.group)
+                o.copy_(h)
+            return lambda: None
+        with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+            for o, i in zip(outs, ins):
+                dist.all_gather_into_tensor(o, i, group=self.group)
+        return cm.wait
+
     def all_reduce_min(self, t):
         return self._run(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.group), t)
 

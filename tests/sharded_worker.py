@@ -191,6 +191,55 @@ def gpu_bf16_fused_sharded(rank, world):
             assert_close(p, ref, 1e-4, 0.3 * 1e-3, f"{kind} param {k}")
 
 
+def gpu_exchange_forms(rank, world):
+    """The two forms of the pipelined exchange — one fp32 all-reduce per layer group with the whole loss on every rank, and
+    reduce-scatter + loss on this rank's token block + all-gather of the 16-bit gradient rows — give the same step: loss to
+    fp64-sum rounding, the reconstruction bit for bit (the reduce-scatter adds the same partial sums), the gathered
+    gradient rows bit for bit (same kernel on the same values), parameters after three Adam steps equal."""
+    from crosslayer_transcoder_amd import engine, precision
+    from crosslayer_transcoder_amd.parallel import FeatureShard, shard_module
+    from tests.build_cases import build_module
+    from tests.golden_cases import assert_close
+    B, L, d, F = 512, 5, 128, 1024
+    g = torch.Generator().manual_seed(23)
+    batches = [torch.randn(B, 2, L, d, generator=g) for _ in range(3)]
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.zeros(L, d)}
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "batchtopk", "k": 8, "e": 0.1},
+                    "loss": {"kind": "base"}}, "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
+            "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
+    for prec in ("bf16-mixed", "32"):
+        runs = {}
+        for split in (False, True):
+            keep, engine.EXCHANGE_SPLIT = engine.EXCHANGE_SPLIT, split
+            try:
+                mod = build_module(case, "cuda:0")
+                shard = FeatureShard(F, keep_single=KEEP_SINGLE)
+                shard_module(mod, shard)
+                opt = mod.configure_optimizers()
+                losses, recs = [], []
+                with precision(prec):
+                    for t, b in enumerate(batches):
+                        losses.append(float(mod.fused_train_step(b.cuda(), t, opt)))
+                        recs.append(mod.last_step["recons_norm"].clone())       # (split form: a collective, on every rank)
+                runs[split] = (losses, recs, {k: p.detach().clone() for k, p in mod.model.named_parameters()})
+            finally:
+                engine.EXCHANGE_SPLIT = keep
+        (l0, r0, p0), (l1, r1, p1) = runs[False], runs[True]
+        for t in range(len(batches)):
+            assert abs(l0[t] - l1[t]) <= 1e-6 * abs(l0[t]), f"{prec} loss step {t}: {l0[t]} vs {l1[t]}"
+            if world <= 2 and t == 0:    # (two addends: any summation order gives the same bits)
+                assert torch.equal(r0[t], r1[t]), f"{prec}: reconstruction differs at step {t}"
+            else:                        # (later steps: decoder.b has moved by a differently rounded gradient, see below)
+                assert_close(r1[t], r0[t], 1e-4, 1e-5, f"{prec} recons step {t}")
+        for k in p0:
+            # decoder.b's gradient is a column sum taken per token block and added over ranks in the split form; Adam's first
+            # steps are sign-like, so a rounding flip moves a weight by a fraction of lr (allowance of the golden-trajectory tests)
+            assert_close(p1[k], p0[k], 1e-4, 0.3 * 1e-3, f"{prec} param {k}")
+
+
 def gpu_fp16_overflow_on_one_shard(rank, world):
     """`precision: "16-mixed"` under feature sharding: an fp16 overflow that only ONE rank's shard produces (a decoder weight
     too large for fp16 in the last rank's slice: the 16-bit shadow cast raises that rank's flag) must skip the step on EVERY
@@ -465,6 +514,27 @@ def sim_rows_selection(rank, world):
         assert torch.equal(result["feat"], want), f"rows trial {trial} rank {rank}: sharded per-row selection differs from the oracle"
 
 
+def sim_row_exchange(rank, world):
+    """FeatureShard.reduce_scatter_rows_async / all_gather_rows_async (the split exchange's two collectives) on host tensors."""
+    from crosslayer_transcoder_amd.parallel import FeatureShard
+    shard = FeatureShard(8 * world, rank=rank, world=world)
+    rows, d, nl = 6 * world, 5, 3
+    full = [torch.arange(rows * d, dtype=torch.float32).view(rows, d) * (l + 1) + 100.0 * r for l in range(nl) for r in [rank]]
+    outs = [torch.empty(rows // world, d) for _ in range(nl)]
+    shard.reduce_scatter_rows_async(outs, [f.clone() for f in full])()
+    for l in range(nl):
+        want = sum(torch.arange(rows * d, dtype=torch.float32).view(rows, d) * (l + 1) + 100.0 * r for r in range(world))
+        assert torch.equal(outs[l], want[rank * 6:(rank + 1) * 6]), f"reduce-scatter rows, layer {l}"
+    for dt in (torch.float32, torch.bfloat16):
+        mine = [(o * 0.5 + rank).to(dt) for o in outs]
+        got = [torch.empty(rows, d, dtype=dt) for _ in range(nl)]
+        shard.all_gather_rows_async(got, mine)()
+        for l in range(nl):
+            want = sum(torch.arange(rows * d, dtype=torch.float32).view(rows, d) * (l + 1) + 100.0 * r for r in range(world))
+            want = torch.cat([(want[r * 6:(r + 1) * 6] * 0.5 + r).to(dt) for r in range(world)])
+            assert torch.equal(got[l], want), f"all-gather rows {dt}, layer {l}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sim", action="store_true")
@@ -484,12 +554,14 @@ def main():
         if args.sim:
             sim_selection(rank, world)
             sim_rows_selection(rank, world)
+            sim_row_exchange(rank, world)
         else:
             if args.backend == "gloo":
                 torch.cuda.set_device(0)
             gpu_selection_ties(rank, world)
             gpu_list_capacity_overflow(rank, world)
             gpu_bf16_fused_sharded(rank, world)
+            gpu_exchange_forms(rank, world)
             gpu_fp16_overflow_on_one_shard(rank, world)
             gpu_save_sharded(rank, world)
             from crosslayer_transcoder_amd import engine
