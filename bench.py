@@ -373,15 +373,23 @@ def main():
             mod.fused_train_step(nxt(), step, opt, sched)
         step += 1
 
+    def density():
+        """Active share of the last step's lists (a thresholding sparsifier's active set shrinks while it trains: the timed
+        window is described by the value before its first and after its last step)."""
+        S = (getattr(mod, "last_step", None) or {}).get("lists")
+        return None if S is None else round(float(S.total) / (args.batch * args.layers * (args.features // max(world, 1))), 6)
+
     for _ in range(args.warmup):
         one_step()
     barrier()
+    density_first = density()
     engine.STATS["select_fallbacks"] = engine.STATS["fused_select_steps"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    density_last = density()
     stats = dict(engine.STATS)
     if dist is not None:
         tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -418,8 +426,7 @@ def main():
                    "fused_select_steps": stats.get("fused_select_steps", 0), "select_fallbacks": stats.get("select_fallbacks", 0),
                    "select_drift": (lambda t: None if t is None else [round(float(v), 5) for v in t[: t.numel() // 2].tolist()])(
                        getattr(mod.model.nonlinearity, "_kth_drift", None)),
-                   "list_density": (lambda S: None if S is None else round(float(S.total) / (args.batch * L * (F // max(world, 1))), 6))(
-                       mod.last_step.get("lists")),
+                   "list_density": density_last, "list_density_first": density_first,
                    "loss": float(mod.last_step["loss"])},
     }
     ms_ = torch.cuda.memory_stats(device)

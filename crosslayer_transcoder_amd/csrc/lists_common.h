@@ -418,7 +418,7 @@ __global__ __launch_bounds__(LTPB) void fill_cols_kernel(const uint32_t* __restr
 }
 
 // order each column's entries by token.  Short columns: one thread, insertion sort.  Longer columns are queued for
-// sort_long_cols_kernel: up to MIDCOL_MAX entries one wave per column (rank counting), beyond that a block (bitonic in LDS).
+// sort_mid_cols_kernel (up to MIDCOL_MAX entries: one wave per column, rank counting) / sort_long_cols_kernel (a block, bitonic in LDS).
 constexpr int SHORT_COL = 24, MIDCOL_MAX = 1024, LONGCOL_MAX = 4096;
 __global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int ncols, int32_t* __restrict__ tok,
                                  float* __restrict__ val, int32_t* __restrict__ ent, int32_t* __restrict__ long_list,
@@ -437,6 +437,65 @@ __global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int nco
     }
 }
 
+// columns of SHORT_COL < n <= MIDCOL_MAX entries: one WAVE each, no block barrier — the keys of a list are distinct (a token / a
+// column occurs once), so an entry's place is the number of smaller keys.  Up to 64 entries: one entry per lane, the keys passed
+// round by v_readlane (no LDS at all); beyond: every lane counts for its (up to 16) entries against the list, read key by key
+// from the wave's LDS copy.  Entries go straight to their places.  (16 KB of LDS per block: ten blocks per CU — the column
+// queue of a thresholding sparsifier at 0.5 % active holds most of the L*F columns, and a wave's work per column is one
+// round trip to memory.)
+__global__ __launch_bounds__(LTPB) void sort_mid_cols_kernel(const uint32_t* __restrict__ col_start, int32_t* __restrict__ tok,
+                                                            float* __restrict__ val, int32_t* __restrict__ ent,
+                                                            const int32_t* __restrict__ long_list,
+                                                            const uint32_t* __restrict__ long_count, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ int32_t wtok_all[(LTPB / 64) * MIDCOL_MAX];
+    const uint32_t nl = *long_count;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t* wtok = wtok_all + wv * MIDCOL_MAX;
+    for (uint32_t q = blockIdx.x * (LTPB / 64) + wv; q < nl; q += gridDim.x * (LTPB / 64)) {
+        const int c = __builtin_amdgcn_readfirstlane(long_list[q]);
+        const uint32_t s = __builtin_amdgcn_readfirstlane(col_start[c]);
+        const uint32_t n = __builtin_amdgcn_readfirstlane(col_start[c + 1]) - s;
+        if (n > MIDCOL_MAX) continue;
+        if (n <= 64) {
+            const bool in = (uint32_t)lane < n;
+            const int32_t t = in ? tok[s + lane] : 0x7fffffff;
+            const float v = in ? val[s + lane] : 0.0f;
+            const int32_t en = (in && ent) ? ent[s + lane] : 0;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(t, j) < t ? 1u : 0u;
+            if (in) { tok[s + rank] = t; val[s + rank] = v; if (ent) ent[s + rank] = en; }
+            continue;
+        }
+        const int E = (int)((n + 63) >> 6);
+        int32_t t[MIDCOL_MAX / 64], en[MIDCOL_MAX / 64];
+        float v[MIDCOL_MAX / 64];
+        uint32_t rank[MIDCOL_MAX / 64];
+#pragma unroll
+        for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+            const uint32_t i = (uint32_t)e * 64 + lane;
+            rank[e] = 0;
+            if (e < E && i < n) { t[e] = tok[s + i]; v[e] = val[s + i]; en[e] = ent ? ent[s + i] : 0; wtok[i] = t[e]; }
+            else t[e] = 0x7fffffff;
+        }
+        __builtin_amdgcn_wave_barrier();               // (the copy is this wave's own: LDS serves a wave's accesses in order)
+        for (uint32_t j = 0; j < n; ++j) {
+            const int32_t tj = wtok[j];
+#pragma unroll
+            for (int e = 0; e < MIDCOL_MAX / 64; ++e) if (e < E) rank[e] += tj < t[e] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+            const uint32_t i = (uint32_t)e * 64 + lane;
+            if (e < E && i < n) { tok[s + rank[e]] = t[e]; val[s + rank[e]] = v[e]; if (ent) ent[s + rank[e]] = en[e]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// columns of MIDCOL_MAX < n <= LONGCOL_MAX entries: a block each (bitonic in LDS).  The queue is read LTPB entries at a time by
+// the whole block, which keeps the few columns of that length in a small LDS queue: a block does not pay a dependent
+// round trip to memory per queue entry that is not its business
 __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __restrict__ col_start, int32_t* __restrict__ tok,
                                                              float* __restrict__ val, int32_t* __restrict__ ent,
                                                              const int32_t* __restrict__ long_list,
@@ -445,72 +504,54 @@ __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __
     __shared__ unsigned long long key[LONGCOL_MAX];     // (token << 32) | position within the column
     __shared__ float sval[LONGCOL_MAX];
     __shared__ int32_t sent[LONGCOL_MAX];
+    __shared__ int32_t mine[LTPB];
+    __shared__ uint32_t nmine;
     const uint32_t nl = *long_count;
-    // columns of up to MIDCOL_MAX entries: one WAVE each, no block barrier — the keys of a list are distinct (a token / a column
-    // occurs once), so an entry's place is the number of smaller keys: every lane counts that for its (up to 16) entries
-    // against the list, read key by key from the wave's LDS copy, and stores them straight to their places
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        int32_t* wtok = reinterpret_cast<int32_t*>(key) + wv * MIDCOL_MAX;
-        for (uint32_t q = blockIdx.x * (LTPB / 64) + wv; q < nl; q += gridDim.x * (LTPB / 64)) {
-            const int c = long_list[q];
+    for (uint32_t base = blockIdx.x * LTPB; base < nl; base += gridDim.x * LTPB) {
+        if (threadIdx.x == 0) nmine = 0;
+        __syncthreads();
+        if (base + threadIdx.x < nl) {
+            const int c = long_list[base + threadIdx.x];
+            const uint32_t n = col_start[c + 1] - col_start[c];
+            if (n > MIDCOL_MAX && n <= LONGCOL_MAX) mine[atomicAdd(&nmine, 1u)] = c;    // (beyond LONGCOL_MAX: left in arrival
+        }                                                                               //  order — still correct, not bit-reproducible)
+        __syncthreads();
+        const uint32_t m = nmine;
+        for (uint32_t k0 = 0; k0 < m; ++k0) {
+            const int c = mine[k0];
             const uint32_t s = col_start[c], n = col_start[c + 1] - s;
-            if (n > MIDCOL_MAX) continue;
-            const int E = (int)((n + 63) >> 6);
-            int32_t t[MIDCOL_MAX / 64], en[MIDCOL_MAX / 64];
-            float v[MIDCOL_MAX / 64];
-            uint32_t rank[MIDCOL_MAX / 64];
-#pragma unroll
-            for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
-                const uint32_t i = (uint32_t)e * 64 + lane;
-                rank[e] = 0;
-                if (e < E && i < n) { t[e] = tok[s + i]; v[e] = val[s + i]; en[e] = ent ? ent[s + i] : 0; wtok[i] = t[e]; }
-                else t[e] = 0x7fffffff;
+            uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+            for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
+                key[i] = i < n ? (((unsigned long long)(uint32_t)tok[s + i] << 32) | i) : ~0ull;
+                if (i < n) { sval[i] = val[s + i]; sent[i] = ent ? ent[s + i] : 0; }
             }
-            __builtin_amdgcn_wave_barrier();               // (the copy is this wave's own: LDS serves a wave's accesses in order)
-            for (uint32_t j = 0; j < n; ++j) {
-                const int32_t tj = wtok[j];
-#pragma unroll
-                for (int e = 0; e < MIDCOL_MAX / 64; ++e) if (e < E) rank[e] += tj < t[e] ? 1u : 0u;
-            }
-#pragma unroll
-            for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
-                const uint32_t i = (uint32_t)e * 64 + lane;
-                if (e < E && i < n) { tok[s + rank[e]] = t[e]; val[s + rank[e]] = v[e]; if (ent) ent[s + rank[e]] = en[e]; }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    for (uint32_t q = blockIdx.x; q < nl; q += gridDim.x) {
-        const int c = long_list[q];
-        const uint32_t s = col_start[c], n = col_start[c + 1] - s;
-        if (n <= MIDCOL_MAX) continue;                  // (done above)
-        if (n > LONGCOL_MAX) continue;                  // left in arrival order (still correct, not bit-reproducible)
-        uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
-        for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
-            key[i] = i < n ? (((unsigned long long)(uint32_t)tok[s + i] << 32) | i) : ~0ull;
-            if (i < n) { sval[i] = val[s + i]; sent[i] = ent ? ent[s + i] : 0; }
-        }
-        __syncthreads();
-        for (uint32_t k = 2; k <= np2; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
-                    const uint32_t ixj = i ^ j;
-                    if (ixj > i) {
-                        const bool up = (i & k) == 0;
-                        const unsigned long long a = key[i], b = key[ixj];
-                        if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+            __syncthreads();
+            for (uint32_t k = 2; k <= np2; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = threadIdx.x; i < np2; i += LTPB) {
+                        const uint32_t ixj = i ^ j;
+                        if (ixj > i) {
+                            const bool up = (i & k) == 0;
+                            const unsigned long long a = key[i], b = key[ixj];
+                            if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += LTPB) {
+                const uint32_t src = (uint32_t)(key[i] & 0xffffffffu);
+                tok[s + i] = (int32_t)(key[i] >> 32); val[s + i] = sval[src]; if (ent) ent[s + i] = sent[src];
             }
-        for (uint32_t i = threadIdx.x; i < n; i += LTPB) {
-            const uint32_t src = (uint32_t)(key[i] & 0xffffffffu);
-            tok[s + i] = (int32_t)(key[i] >> 32); val[s + i] = sval[src]; if (ent) ent[s + i] = sent[src];
+            __syncthreads();
         }
-        __syncthreads();
     }
+}
+
+// the queue of sort_cols_kernel: mid columns by waves, long columns by blocks
+static inline void launch_sort_queued_cols(hipStream_t st, const uint32_t* col_start, int32_t* tok, float* val, int32_t* ent,
+                                           const int32_t* long_list, const uint32_t* long_count, const int32_t* gate, int gate_on) {
+    hipLaunchKernelGGL(sort_mid_cols_kernel, dim3(2048), dim3(LTPB), 0, st, col_start, tok, val, ent, long_list, long_count, gate, gate_on);
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(LTPB), 0, st, col_start, tok, val, ent, long_list, long_count, gate, gate_on);
 }
 
 

@@ -572,8 +572,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                a.ent_col, a.ent_val);
             hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
                                (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
-            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
-                               long_list, &head->long_rows, gate, 0);
+            launch_sort_queued_cols(st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
         } else if (stage == 4 && local_radix) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             // (the tie pass still counts what this shard will emit, for the list-capacity gate; its tie lists are not used)
@@ -610,8 +609,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                a.ent_col, a.ent_val);
             hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
                                (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
-            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(TPB), 0, st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr,
-                               long_list, &head->long_rows, gate, 0);
+            launch_sort_queued_cols(st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
         }
         if (stage != last_stage) continue;
         // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
@@ -620,8 +618,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                            a.col_start, col_cur, a.csc_tok, a.csc_val, a.csc_ent, gate, 0);
         hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, a.col_start, ncols, a.csc_tok, a.csc_val,
                            a.csc_ent, long_list, &head->long_cols, gate, 0);
-        hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, a.col_start, a.csc_tok, a.csc_val, a.csc_ent, long_list,
-                           &head->long_cols, gate, 0);
+        launch_sort_queued_cols(st, a.col_start, a.csc_tok, a.csc_val, a.csc_ent, long_list, &head->long_cols, gate, 0);
         CLT_LAUNCH_CHECK();
         if (mode != 0 && a.sd.world == 1 && a.dense_scratch) {   // exhaustive path, enqueued always, runs only when gated in
             const float* src = a.x;
@@ -777,8 +774,7 @@ int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int 
                                col_cur, csc_tok, csc_val, csc_ent, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val, csc_ent,
                                long_list, &head->long_cols, (const int32_t*)nullptr, 0);
-            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
-                               &head->long_cols, (const int32_t*)nullptr, 0);
+            launch_sort_queued_cols(st, col_start, csc_tok, csc_val, csc_ent, long_list, &head->long_cols, (const int32_t*)nullptr, 0);
         }
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;

@@ -219,8 +219,7 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
                                csc_tok, csc_val, csc_ent, (const int32_t*)nullptr, 0);
             hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val,
                                csc_ent, long_list, &head->long_cols, (const int32_t*)nullptr, 0);
-            hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
-                               &head->long_cols, (const int32_t*)nullptr, 0);
+            launch_sort_queued_cols(st, col_start, csc_tok, csc_val, csc_ent, long_list, &head->long_cols, (const int32_t*)nullptr, 0);
         }
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;

@@ -924,8 +924,7 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
                        col_start, cursor, csc_tok, csc_val, csc_ent, gate, 1);
     hipLaunchKernelGGL(sort_cols_kernel, dim3((ncols + TPB - 1) / TPB), dim3(TPB), 0, st, col_start, ncols, csc_tok, csc_val,
                        csc_ent, long_list, long_count, gate, 1);
-    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(TPB), 0, st, col_start, csc_tok, csc_val, csc_ent, long_list,
-                       long_count, gate, 1);
+    launch_sort_queued_cols(st, col_start, csc_tok, csc_val, csc_ent, long_list, long_count, gate, 1);
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
 
