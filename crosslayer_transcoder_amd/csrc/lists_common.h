@@ -443,6 +443,44 @@ __global__ void sort_cols_kernel(const uint32_t* __restrict__ col_start, int nco
 // from the wave's LDS copy.  Entries go straight to their places.  (16 KB of LDS per block: ten blocks per CU — the column
 // queue of a thresholding sparsifier at 0.5 % active holds most of the L*F columns, and a wave's work per column is one
 // round trip to memory.)
+// (one wave; s, n wave-uniform, 2 <= n <= MIDCOL_MAX; wtok: MIDCOL_MAX words of LDS of this wave's own)
+__device__ __forceinline__ void wave_sort_list(uint32_t s, uint32_t n, int32_t* __restrict__ tok, float* __restrict__ val,
+                                               int32_t* __restrict__ ent, int32_t* wtok, int lane) {
+    if (n <= 64) {
+        const bool in = (uint32_t)lane < n;
+        const int32_t t = in ? tok[s + lane] : 0x7fffffff;
+        const float v = in ? val[s + lane] : 0.0f;
+        const int32_t en = (in && ent) ? ent[s + lane] : 0;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(t, j) < t ? 1u : 0u;
+        if (in) { tok[s + rank] = t; val[s + rank] = v; if (ent) ent[s + rank] = en; }
+        return;
+    }
+    const int E = (int)((n + 63) >> 6);
+    int32_t t[MIDCOL_MAX / 64], en[MIDCOL_MAX / 64];
+    float v[MIDCOL_MAX / 64];
+    uint32_t rank[MIDCOL_MAX / 64];
+#pragma unroll
+    for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+        const uint32_t i = (uint32_t)e * 64 + lane;
+        rank[e] = 0;
+        if (e < E && i < n) { t[e] = tok[s + i]; v[e] = val[s + i]; en[e] = ent ? ent[s + i] : 0; wtok[i] = t[e]; }
+        else t[e] = 0x7fffffff;
+    }
+    __builtin_amdgcn_wave_barrier();               // (the copy is this wave's own: LDS serves a wave's accesses in order)
+    for (uint32_t j = 0; j < n; ++j) {
+        const int32_t tj = wtok[j];
+#pragma unroll
+        for (int e = 0; e < MIDCOL_MAX / 64; ++e) if (e < E) rank[e] += tj < t[e] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
+        const uint32_t i = (uint32_t)e * 64 + lane;
+        if (e < E && i < n) { tok[s + rank[e]] = t[e]; val[s + rank[e]] = v[e]; if (ent) ent[s + rank[e]] = en[e]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(LTPB) void sort_mid_cols_kernel(const uint32_t* __restrict__ col_start, int32_t* __restrict__ tok,
                                                             float* __restrict__ val, int32_t* __restrict__ ent,
                                                             const int32_t* __restrict__ long_list,
@@ -451,46 +489,30 @@ __global__ __launch_bounds__(LTPB) void sort_mid_cols_kernel(const uint32_t* __r
     __shared__ int32_t wtok_all[(LTPB / 64) * MIDCOL_MAX];
     const uint32_t nl = *long_count;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int32_t* wtok = wtok_all + wv * MIDCOL_MAX;
     for (uint32_t q = blockIdx.x * (LTPB / 64) + wv; q < nl; q += gridDim.x * (LTPB / 64)) {
         const int c = __builtin_amdgcn_readfirstlane(long_list[q]);
         const uint32_t s = __builtin_amdgcn_readfirstlane(col_start[c]);
         const uint32_t n = __builtin_amdgcn_readfirstlane(col_start[c + 1]) - s;
         if (n > MIDCOL_MAX) continue;
-        if (n <= 64) {
-            const bool in = (uint32_t)lane < n;
-            const int32_t t = in ? tok[s + lane] : 0x7fffffff;
-            const float v = in ? val[s + lane] : 0.0f;
-            const int32_t en = (in && ent) ? ent[s + lane] : 0;
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(t, j) < t ? 1u : 0u;
-            if (in) { tok[s + rank] = t; val[s + rank] = v; if (ent) ent[s + rank] = en; }
-            continue;
-        }
-        const int E = (int)((n + 63) >> 6);
-        int32_t t[MIDCOL_MAX / 64], en[MIDCOL_MAX / 64];
-        float v[MIDCOL_MAX / 64];
-        uint32_t rank[MIDCOL_MAX / 64];
-#pragma unroll
-        for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
-            const uint32_t i = (uint32_t)e * 64 + lane;
-            rank[e] = 0;
-            if (e < E && i < n) { t[e] = tok[s + i]; v[e] = val[s + i]; en[e] = ent ? ent[s + i] : 0; wtok[i] = t[e]; }
-            else t[e] = 0x7fffffff;
-        }
-        __builtin_amdgcn_wave_barrier();               // (the copy is this wave's own: LDS serves a wave's accesses in order)
-        for (uint32_t j = 0; j < n; ++j) {
-            const int32_t tj = wtok[j];
-#pragma unroll
-            for (int e = 0; e < MIDCOL_MAX / 64; ++e) if (e < E) rank[e] += tj < t[e] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < MIDCOL_MAX / 64; ++e) {
-            const uint32_t i = (uint32_t)e * 64 + lane;
-            if (e < E && i < n) { tok[s + rank[e]] = t[e]; val[s + rank[e]] = v[e]; if (ent) ent[s + rank[e]] = en[e]; }
-        }
-        __builtin_amdgcn_wave_barrier();
+        wave_sort_list(s, n, tok, val, ent, wtok_all + wv * MIDCOL_MAX, lane);
     }
+}
+
+// the rows of a token-major list (a dozen or more entries each, unlike most columns): one wave per row straight away — a
+// thread per row walks its own 100-odd bytes and nothing coalesces.  Rows beyond MIDCOL_MAX are queued for sort_long_cols_kernel
+__global__ __launch_bounds__(LTPB) void sort_rows_kernel(const uint32_t* __restrict__ row_start, int rows, int32_t* __restrict__ col,
+                                                        float* __restrict__ val, int32_t* __restrict__ long_list,
+                                                        uint32_t* __restrict__ long_count, const int32_t* __restrict__ gate, int gate_on) {
+    if (gate && (*gate != 0) != (gate_on != 0)) return;
+    __shared__ int32_t wtok_all[(LTPB / 64) * MIDCOL_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * (LTPB / 64) + wv;
+    if (row >= rows) return;
+    const uint32_t s = __builtin_amdgcn_readfirstlane(row_start[row]);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(row_start[row + 1]) - s;
+    if (n < 2) return;
+    if (n > MIDCOL_MAX) { if (lane == 0) long_list[atomicAdd(long_count, 1u)] = row; return; }
+    wave_sort_list(s, n, col, val, (int32_t*)nullptr, wtok_all + wv * MIDCOL_MAX, lane);
 }
 
 // columns of MIDCOL_MAX < n <= LONGCOL_MAX entries: a block each (bitonic in LDS).  The queue is read LTPB entries at a time by
@@ -545,6 +567,15 @@ __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __
             __syncthreads();
         }
     }
+}
+
+// rows of a token-major list in column order
+static inline void launch_sort_rows(hipStream_t st, const uint32_t* row_start, int rows, int32_t* col, float* val, int32_t* long_list,
+                                    uint32_t* long_count, const int32_t* gate, int gate_on) {
+    hipLaunchKernelGGL(sort_rows_kernel, dim3((rows + LTPB / 64 - 1) / (LTPB / 64)), dim3(LTPB), 0, st, row_start, rows, col, val, long_list,
+                       long_count, gate, gate_on);
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(LTPB), 0, st, row_start, col, val, (int32_t*)nullptr, long_list, long_count,
+                       gate, gate_on);
 }
 
 // the queue of sort_cols_kernel: mid columns by waves, long columns by blocks

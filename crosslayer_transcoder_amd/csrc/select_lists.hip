@@ -570,9 +570,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);
-            hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
-                               (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
-            launch_sort_queued_cols(st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
+            launch_sort_rows(st, a.row_start, rows, a.ent_col, a.ent_val, long_list, &head->long_rows, gate, 0);
         } else if (stage == 4 && local_radix) {
             hipLaunchKernelGGL(seg_find_kernel, dim3(p.S), dim3(TPB), 0, st, state, ghist, 2, gate, 0);
             // (the tie pass still counts what this shard will emit, for the list-capacity gate; its tie lists are not used)
@@ -607,9 +605,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);
-            hipLaunchKernelGGL(sort_cols_kernel, dim3((rows + TPB - 1) / TPB), dim3(TPB), 0, st, a.row_start, rows, a.ent_col, a.ent_val,
-                               (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
-            launch_sort_queued_cols(st, a.row_start, a.ent_col, a.ent_val, (int32_t*)nullptr, long_list, &head->long_rows, gate, 0);
+            launch_sort_rows(st, a.row_start, rows, a.ent_col, a.ent_val, long_list, &head->long_rows, gate, 0);
         }
         if (stage != last_stage) continue;
         // feature-major lists from the finished CSR (column counts were accumulated by the emitters)
