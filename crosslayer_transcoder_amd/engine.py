@@ -632,6 +632,315 @@ class _VoidAttempt(Exception):
     """The fused encoder+select attempt of this step did not hold (learnt late, see _settle): run the step again unfused."""
 
 
+class _StepCtx:
+    """What the phases of one training step share and none of them changes: the module's parts, the shapes, the precision
+    mode, the standardized inputs."""
+    __slots__ = ("mod", "enc", "dec", "nl", "ost", "optimizer", "shard", "dev", "Bn", "L", "d", "F", "N", "bf16", "fp16", "flag",
+                 "kind", "xo", "xs32", "xs16", "mlp_out", "batch_idx")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _aux_forward_lists(c, D, dead, pre_acts, ys, r, g, terms, grads):
+    """TopK-aux pass of the list regime, forward half (clt_lightning.py:539-553): top k_aux of the DEAD features per row, second
+    decoder pass, aux loss; g += g_aux in place.  Either as a dense sub-problem on the compacted dead columns (returns
+    `compact` = (n_pad, cmap, Dc, feat_c, fc16) for _aux_compact_backward) or as a second pair of activation lists (returns
+    S2).  Sets terms["aux"] and the aux part of grads["decoder.b"].  Returns (S2, g_aux, compact)."""
+    mod, enc, dec, shard, dev, bf16, xo = c.mod, c.enc, c.dec, c.shard, c.dev, c.bf16, c.xo
+    Bn, L, d, F, N = c.Bn, c.L, c.d, c.F, c.N
+    S2 = cx = None
+    aux = mod.topk_aux
+    if COMPACT_AUX and isinstance(aux, PerLayerTopK) and 0 < aux.k <= 2048:
+        cx = ops.compact_columns(dead)                      # one host read: the per-layer dead counts
+        if cx is not None and cx[0] > COMPACT_AUX_MAX_SHARE * F:
+            cx = None
+        if cx is not None:
+            # gathered weights (fp32 + bf16 + bf16 transposed) + their fp32 gradients + compact activations
+            rows_c = sum(w.shape[0] for w in D.W32) * cx[0]
+            need = rows_c * d * 12 + Bn * L * cx[0] * 16
+            if need > 0.8 * torch.cuda.mem_get_info(dev)[0]:
+                cx = None                                   # not enough HBM left: the activation-list form
+        if shard is not None:                               # both forms hold collectives: every rank takes the same one
+            agreed = torch.tensor([0 if cx is None else 1], dtype=torch.int32, device=dev)
+            if int(shard.all_reduce_min(agreed)) == 0:
+                cx = None
+    if cx is not None:
+        # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
+        n_pad, cidx, cmap = cx
+        # (16-bit modes: the dead columns' pre-activations come from the encoder GEMM on the gathered weight rows — same
+        # kernel, same bits — instead of a second read of `pre`: every 64-byte line of it holds a dead column or two)
+        if bf16 and F % 4 == 0 and d % 8 == 0 and Bn * n_pad >= 256 * 256 and COMPACT_AUX_GEMM_COLUMNS:
+            pre_c = ops.encoder_fwd_columns(xo, enc.Wt, enc.b, cidx)
+        else:
+            pre_c = ops.gather_cols(pre_acts(), cidx, float("-inf"))
+        if shard is None:
+            feat_c = ops.topk_rows(pre_c, min(aux.k, n_pad))
+        else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
+            Sc = ops.select_rows_sharded(pre_c, aux.k, shard, local_columns=True)
+            feat_c = ops.sparse_scatter_dense(Sc, Sc.csc_val)
+        if bf16 and COMPACT_AUX_FUSED_OPERANDS and d % 4 == 0 and all(w.is_contiguous() for w in D.W32):
+            # 16-bit operand forms of the dead rows straight from the decoder matrices (no gathered fp32 copies)
+            Dc = _Decoder(_CompactDecoder(dec, [None] * len(D.W32), n_pad), shard, clt=D.clt)
+            prepped = [ops.weight_prep_gather_bf16(w, cidx) for w in D.W32]
+            Dc._Wop, Dc._WT = [p[0] for p in prepped], [p[1] for p in prepped]
+        else:
+            Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
+        # 16-bit modes: both GEMM operand forms of the compact features (row-major for the forward, transposed for the
+        # weight gradient) from ONE read of them (the ReLU tile pass of the dense regime: feat_c >= 0 already)
+        fc16 = ops.jumprelu_fwd_bf16(feat_c, None)[:2] if (bf16 and COMPACT_AUX_FUSED_OPERANDS and Bn % 8 == 0) else None
+        aux_r = Dc.fwd(feat_c, feat_op=fc16[0] if fc16 is not None else None)
+    else:
+        S2 = _select_lists(aux, pre_acts(), dead, shard)
+        aux_r = D.sparse_fwd(S2)
+    aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
+    terms["aux"] = (aux_sum[0] / N).float()
+    grads["decoder.b"] = ops.column_sum(g_aux)
+    compact = (n_pad, cmap, Dc, feat_c, fc16) if cx is not None else None
+    return S2, g_aux, compact
+
+
+def _aux_compact_backward(c, compact, g_aux):
+    """Backward of the compacted aux pass: the dead rows' decoder gradients and the dead columns' encoder gradients, compact; they
+    re-enter the Adam row passes through the row -> compact-row map.  Returns (extra_dec, extra_enc)."""
+    n_pad, cmap, Dc, feat_c, fc16 = compact
+    Bn, L, d, bf16, dev, xs32 = c.Bn, c.L, c.d, c.bf16, c.dev, c.xs32
+    gc: Dict[str, torch.Tensor] = {}
+    Dc.wgrad(feat_c, g_aux, gc, featT=fc16[1] if fc16 is not None else None)
+    if fc16 is not None:
+        # masked feature gradient straight to the transposed 16-bit operand + its column sums (no fp32 dpre tensor)
+        dT_c, db_c = ops.mask_positive_t(feat_c, Dc.dgrad(g_aux))
+    else:
+        dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
+        dT_c = ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn) if bf16 else None
+        db_c = ops.column_sum(dpre_c)
+    if bf16:
+        dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=dev)
+        ops.wgrad_t(dT_c, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L, n_pad * Bn, d * Bn)
+    else:
+        dWt_c = ops.encoder_wgrad(xs32, dpre_c)
+    extra_dec = (gc, cmap)
+    extra_enc = (dWt_c.view(-1, d), cmap, db_c.view(-1))
+    return extra_dec, extra_enc
+
+
+def _encoder_pass_lists(c, S, dval, S2, dval2, xsrc, extra_enc, grads):
+    """Encoder weight / bias gradient (+ Adam) of the list regime from d(loss)/d(feature) per list entry."""
+    enc, optimizer, bf16, dev, L, F = c.enc, c.optimizer, c.bf16, c.dev, c.L, c.F
+    # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
+    # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
+    db = torch.empty(L, F, dtype=torch.float32, device=dev)
+    Wt = enc.Wt
+    kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None, extra=extra_enc)
+    if optimizer is not None:
+        kw.update(optimizer.begin_fused(enc.W, storage=Wt))
+        if bf16:
+            kw["shadow"] = _encoder_operand(enc)
+    else:
+        dWt = torch.empty_like(Wt)
+        kw["grad_out"] = dWt
+        grads["encoder.W"] = dWt.permute(0, 2, 1)
+    ops.sparse_row_pass(Wt, S, dval, xsrc, 0, -1, **kw)
+    grads["encoder.b"] = db
+
+
+def _backward_jumprelu(c, D, S, pre, pre_bias, theta, feat, fused_ops, fuse_jump, g, terms, grads, out):
+    """JumpReLU module (clt_lightning.py:420-475): sparsity and pre-activation loss terms, their gradients and the STE backward in
+    one pass over the pre-activations; decoder weight gradients from the lists (S) or the dense GEMMs.  Returns (loss, dpre,
+    dpreT, db): d(loss)/d(pre) as the fp32 tensor or as the transposed 16-bit operand + its column sums."""
+    mod, nl, shard, optimizer, bf16, fp16, flag = c.mod, c.nl, c.shard, c.optimizer, c.bf16, c.fp16, c.flag
+    Bn, L, F = c.Bn, c.L, c.F
+    dpre = dpreT = db = None
+    if not isinstance(nl, (JumpReLU, ReLU)):
+        raise NotImplementedError("JumpReLU loss module needs a JumpReLU/ReLU nonlinearity in the fused step")
+    lam = mod._lambda * (mod.global_step / mod.trainer.max_steps)
+    th = theta if theta is not None else torch.zeros(1, L, F, device=pre.device)
+    bw = nl._bandwidth if theta is not None else 1.0
+    sq = D.sqnorms()
+    g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
+    loss16 = fused_ops is not None or (S is not None and fuse_jump)
+    dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
+    if loss16:
+        sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
+                                                              mod.pre_actv_loss / (Bn * L), bias=pre_bias)
+    else:
+        sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
+                                                    mod.pre_actv_loss / (Bn * L))
+    if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
+        sums = shard.all_reduce_sum(sums.clone())
+        if fp16:                          # d(pre) is per shard: every rank must take the same skip decision
+            agree_on_overflow(shard, flag)
+    if S is not None:
+        # list regime: dW_l[l', i, :] = sum over the tokens where feature (l', i) is active of val * g[tok, l, :], plus the
+        # row's dec_norms term — one streaming pass per decoder matrix, Adam applied in it when an optimizer is handed in
+        D.sparse_wgrad(S, g, grads, optimizer, (dn, sq), g16)
+        out["lists"] = S
+    else:
+        D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
+        D.add_norm_grads(dn, sq, grads, optimizer)
+    grads["decoder.b"] = ops.column_sum(g)
+    if theta is not None:
+        grads["nonlinearity.theta"] = dth
+    terms["sparsity"] = (lam * sums[0] / Bn).float()
+    terms["pre_actv"] = (mod.pre_actv_loss * sums[1] / (Bn * L)).float()
+    terms["weighted_features_mean"] = (sums[2] / (Bn * L * F * (shard.world if shard is not None else 1))).float()
+    terms["sparsity_penalty"] = torch.tensor(lam)
+    loss = terms["mse"] + terms["sparsity"] + terms["pre_actv"]
+    return loss, dpre, dpreT, db
+
+
+def _backward_dense(c, D, pre, feat, theta, dead, ys, r, g, terms, grads):
+    """Dense regime under the base / TopK-aux losses: aux pass (dense selection on the dead columns, second decoder pass),
+    decoder gradients by GEMM, d(loss)/d(pre) through the sparsifier's backward.  Returns (loss, dpre)."""
+    mod, nl, kind, N = c.mod, c.nl, c.kind, c.N
+    if kind == "topk":
+        aux = mod.topk_aux
+        dead_pre = ops.mask_dead(pre, dead)
+        dead_feat = _select(aux, dead_pre)
+        aux_r = D.fwd(dead_feat)
+        aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
+        terms["aux"] = (aux_sum[0] / N).float()
+        loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
+        D.wgrad(dead_feat, g_aux, grads)
+        grads["decoder.b"] = ops.column_sum(g_aux)
+    else:
+        loss = terms["mse"]
+    D.wgrad(feat, g, grads)
+    grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
+    dfeat = D.dgrad(g)
+    if theta is not None:
+        dpre, grads["nonlinearity.theta"] = ops.jumprelu_bwd(pre, theta, nl._bandwidth, dfeat)
+    elif isinstance(nl, ReLU):
+        dpre = ops.relu_bwd(pre, dfeat)
+    else:
+        dpre = ops.mask_positive(feat, dfeat)
+    if kind == "topk":
+        ops.mask_positive(dead_feat, D.dgrad(g_aux), out=dpre, accumulate=True)   # aux path reaches dead entries only
+    return loss, dpre
+
+
+def _encoder_wgrad_dense(c, pre, dpre, dpreT, db, grads):
+    """Encoder weight / bias gradient of the dense regime: contraction over the tokens."""
+    bf16, Bn, L, d, F, xs32, xo = c.bf16, c.Bn, c.L, c.d, c.F, c.xs32, c.xo
+    if bf16:       # dWt[l] [F, d] = dpre[:, l]^T @ xs[:, l], contraction over tokens: both operands token-minor
+        dWt = torch.empty(L, F, d, dtype=torch.float32, device=pre.device)
+        dT = dpreT if dpreT is not None else ops.transpose_cast_2d(dpre).view(L, F, Bn)
+        ops.wgrad_t(dT, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt, L, F * Bn, d * Bn)
+        grads["encoder.W"] = dWt.permute(0, 2, 1)
+    else:
+        grads["encoder.W"] = ops.encoder_wgrad(xo, dpre).permute(0, 2, 1)
+    grads["encoder.b"] = db if dpreT is not None else ops.column_sum(dpre)
+
+
+def _fused_batch_select(c, split_args):
+    """BatchTopK / PerLayerBatchTopK with last step's k-th value known: encoder GEMM whose epilogue files the candidates, exact
+    selection on those (clt_gemm_bf16_select + clt_select_lists_ext_f32).  Returns (lists or None, deferred host read or None);
+    the deferred read raises _VoidAttempt when the bound did not hold."""
+    nl, enc, dec, shard, optimizer, fp16, dev, xo, L, d = c.nl, c.enc, c.dec, c.shard, c.optimizer, c.fp16, c.dev, c.xo, c.L, c.d
+    mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
+    nseg = L if isinstance(nl, PerLayerBatchTopK) else 1
+    drift = getattr(nl, "_kth_drift", None)
+    if ADAPTIVE_SELECT_MARGIN and (drift is None or drift.numel() != 2 * nseg or drift.device != dev):
+        drift = nl._kth_drift = ops.new_select_drift(nseg, dev)
+    # the decoder's gather forward is queued BEFORE the host reads whether the bound held (it only reads the lists, which
+    # are empty after a void attempt): the launch queue does not run dry behind that read — on an 8-way shard, where
+    # every kernel is 8 times shorter, the GPU otherwise idled ~0.2 ms a step there
+    def _spec_fwd(S_):
+        D_ = _Decoder(dec, shard, shadow=optimizer is not None)
+        lm = bool(PIPELINE_EXCHANGE and shard is not None and D_.clt and not fp16)
+        if lm:
+            return (D_, True) + _forward_and_exchange(D_, S_, shard, d, split_args)
+        return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
+
+    S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
+                                      nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
+                                      speculate=_spec_fwd if SPECULATIVE_FORWARD else None, defer=SPECULATIVE_FORWARD)
+    STATS["fused_select_steps"] += 1
+
+    def _settle_select():
+        """The step's one host read: did the bound hold?  Asked as late as possible — before the first kernel that
+        changes module state (dead-feature counters, weights) — so that the forward, the exchange and the first loss
+        kernel are already queued behind the selection and the GPU does not idle while the host waits."""
+        if S.confirm():
+            nl._kth = kth
+            return
+        nl._kth = None
+        STATS["select_fallbacks"] += 1
+        if drift is not None:
+            drift[:nseg] = 0.1               # the bound did not hold: back to the floor for ~30 steps, then tighten again
+        raise _VoidAttempt()
+
+    if SPECULATIVE_FORWARD:
+        return S, _settle_select
+    if S is not None:
+        nl._kth = kth
+    else:
+        STATS["select_fallbacks"] += 1
+        if drift is not None:
+            drift[:nseg] = 0.1
+    return S, None
+
+
+def _fused_rows_select(c):
+    """PerLayerTopK fused with the encoder GEMM (clt_select_rows_ext_f32 + clt_gemm_bf16_select_rows).  Returns (lists, deferred
+    host read); the read raises _VoidAttempt when some row's bound did not hold, and the rerun of the step is unfused."""
+    mod, nl, enc, dec, optimizer, xo, d, batch_idx = c.mod, c.nl, c.enc, c.dec, c.optimizer, c.xo, c.d, c.batch_idx
+    # per-row TopK without the pre-activation tensor: lower bound of every row from a narrow GEMM on a rotating 1/16 sample
+    # of the features, candidates filed per row by the full GEMM's epilogue, exact selection on those
+    def _spec_rows(S_):
+        D_ = _Decoder(dec, None, shadow=optimizer is not None)
+        return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
+
+    S = ops.encoder_select_rows_lists(xo, _encoder_operand(enc), enc.b, nl.k, offset=batch_idx,
+                                      speculate=_spec_rows if SPECULATIVE_FORWARD else None)
+    STATS["fused_select_steps"] += 1
+
+    def _settle_rows():
+        if S.confirm():
+            return
+        STATS["select_fallbacks"] += 1
+        mod._rows_unfused_once = True                # some row's bound did not hold: this step again, unfused
+        raise _VoidAttempt()
+
+    return S, _settle_rows
+
+
+def _group_slabs(c, groups, waits, ex, r_lm):
+    """Pipelined exchange, backward half.  Returns (slabs, loss_parts, b_grad): slabs(l) makes the current stream wait for layer
+    l's group — in the all-reduce form it then computes the group's loss partial, gradient slabs and bias-gradient rows; in the
+    split form (ex) those came with the exchange — and returns layer l's gradient slab [B, d]; the weight passes call it right
+    before the pass of W_l.  loss_parts fp64 [L] (one entry per group used), b_grad [L, d]."""
+    ost, mlp_out, bf16, dev, Bn, L, d, N = c.ost, c.mlp_out, c.bf16, c.dev, c.Bn, c.L, c.d, c.N
+    if ex is not None:                                   # split form: the loss ran on this rank's token block, per group
+        loss_parts, b_grad, g_lm = ex.loss_parts, ex.b_grad, ex.g_lm
+    else:
+        loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
+        b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
+        g_lm = torch.empty(L, Bn, d, dtype=ops.op16() if bf16 else torch.float32, device=dev)
+    group_of = {l: gi for gi, (lo, hi) in enumerate(groups) for l in range(lo, hi)}
+    done = set()
+
+    def slabs(l):
+        gi = group_of[l]
+        if gi not in done:                               # first layer of its group: wait for the group's exchange, then its loss
+            done.add(gi)
+            waits[gi]()                                  # (the current stream waits; the host does not)
+            if ex is not None:                           # (... for the group's gathered gradient slabs: nothing left to compute)
+                return g_lm[l]
+            lo, hi = groups[gi]
+            if not (bf16 and ops.mse_bf16_colsum_layers(r_lm[lo:hi], mlp_out[:, lo:hi], ost.mean[lo:hi], ost.std[lo:hi], N,
+                                                        g_lm[lo:hi], b_grad[lo:hi], loss_parts[gi:gi + 1])):
+                for ll in range(lo, hi):                 # generic form, layer by layer (fp32 mode, odd shapes)
+                    ls, gl, _ = ops.mse(r_lm[ll], mlp_out[:, ll], ost.mean[ll], ost.std[ll], True, False, count=N)
+                    loss_parts[gi:gi + 1].add_(ls)
+                    ops.column_sum(gl, b_grad[ll])
+                    g_lm[ll].copy_(ops.cast_bf16(gl) if bf16 else gl)
+        return g_lm[l]
+
+    return slabs, loss_parts, b_grad
+
+
 def training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, sparse: Optional[bool] = None) -> Dict[str, object]:
     try:
         return _training_step(mod, batch, batch_idx, optimizer, sparse)
@@ -707,7 +1016,10 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     # pipelined exchange in its reduce-scatter + all-gather form (every rank decides from the shapes alone)
     split_args = ((mlp_out, ost, Bn * L * d, bf16) if (EXCHANGE_SPLIT and shard is not None and Bn % shard.world == 0
                                                       and (shard.world > 1 or shard.keep_single)) else None)
-    pending = None                               # deferred host read of the fused selection's outcome (see _settle_select)
+    pending = None                               # deferred host read of a fused selection's outcome
+    c = _StepCtx(mod=mod, enc=enc, dec=dec, nl=nl, ost=ost, optimizer=optimizer, shard=shard, dev=dev, Bn=Bn, L=L, d=d, F=F,
+                 N=Bn * L * d, bf16=bf16, fp16=fp16, flag=flag if fp16 else None, kind=kind, xo=xo, xs32=xs32, xs16=xs16,
+                 mlp_out=mlp_out, batch_idx=batch_idx)
     probe = getattr(nl, "_kth_probe", None)
     if probe is not None and probe.value():
         # the last unfused selection ended in its exhaustive fallback, which leaves no k-th key behind: a fused attempt
@@ -716,73 +1028,12 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
     nl._kth_probe = None
     if (sparse and bf16 and kind == "base" and batch_mode and nl.k > 0 and nl.e is not None and FUSE_ENCODER_SELECT
             and getattr(nl, "_kth", None) is not None and d % 8 == 0 and F % 4 == 0):
-        mode = ops.SELECT_LAYER if isinstance(nl, PerLayerBatchTopK) else ops.SELECT_BATCH
-        nseg = L if isinstance(nl, PerLayerBatchTopK) else 1
-        drift = getattr(nl, "_kth_drift", None)
-        if ADAPTIVE_SELECT_MARGIN and (drift is None or drift.numel() != 2 * nseg or drift.device != dev):
-            drift = nl._kth_drift = ops.new_select_drift(nseg, dev)
-        # the decoder's gather forward is queued BEFORE the host reads whether the bound held (it only reads the lists, which
-        # are empty after a void attempt): the launch queue does not run dry behind that read — on an 8-way shard, where
-        # every kernel is 8 times shorter, the GPU otherwise idled ~0.2 ms a step there
-        def _spec_fwd(S_):
-            D_ = _Decoder(dec, shard, shadow=optimizer is not None)
-            lm = bool(PIPELINE_EXCHANGE and shard is not None and D_.clt and not fp16)
-            if lm:
-                return (D_, True) + _forward_and_exchange(D_, S_, shard, d, split_args)
-            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
-
-        S, kth = ops.encoder_select_lists(xo, _encoder_operand(enc), enc.b, nl.k, mode, nl._kth, SELECT_MARGIN, nl.threshold,
-                                          nl.e, shard, drift=drift if ADAPTIVE_SELECT_MARGIN else None,
-                                          speculate=_spec_fwd if SPECULATIVE_FORWARD else None, defer=SPECULATIVE_FORWARD)
-        STATS["fused_select_steps"] += 1
-
-        def _settle_select():
-            """The step's one host read: did the bound hold?  Asked as late as possible — before the first kernel that
-            changes module state (dead-feature counters, weights) — so that the forward, the exchange and the first loss
-            kernel are already queued behind the selection and the GPU does not idle while the host waits."""
-            nonlocal pending
-            pending = None
-            if S.confirm():
-                nl._kth = kth
-                return
-            nl._kth = None
-            STATS["select_fallbacks"] += 1
-            if drift is not None:
-                drift[:nseg] = 0.1               # the bound did not hold: back to the floor for ~30 steps, then tighten again
-            raise _VoidAttempt()
-
-        if SPECULATIVE_FORWARD:
-            pending = _settle_select
-        elif S is not None:
-            nl._kth = kth
-        else:
-            STATS["select_fallbacks"] += 1
-            if drift is not None:
-                drift[:nseg] = 0.1
+        S, pending = _fused_batch_select(c, split_args)
     rows_unfused = getattr(mod, "_rows_unfused_once", False)       # (the rerun after a void per-row attempt)
     mod._rows_unfused_once = False
     if (S is None and sparse and bf16 and kind in ("base", "topk") and isinstance(nl, PerLayerTopK) and shard is None and FUSE_ENCODER_ROWS
             and not rows_unfused and ops.encoder_select_rows_applicable(Bn, L, d, F, nl.k) and _rows_fit(mod, Bn, L, d, F, nl.k, dev)):
-        # per-row TopK without the pre-activation tensor: lower bound of every row from a narrow GEMM on a rotating 1/16 sample
-        # of the features, candidates filed per row by the full GEMM's epilogue, exact selection on those
-        def _spec_rows(S_):
-            D_ = _Decoder(dec, None, shadow=optimizer is not None)
-            return D_, False, ops.sparse_decoder_fwd(S_, D_.pointer_table(), D_._bias(), d, D_.clt, w_bf16=D_.shadow), None, None
-
-        S = ops.encoder_select_rows_lists(xo, _encoder_operand(enc), enc.b, nl.k, offset=batch_idx,
-                                          speculate=_spec_rows if SPECULATIVE_FORWARD else None)
-        STATS["fused_select_steps"] += 1
-
-        def _settle_rows():
-            nonlocal pending
-            pending = None
-            if S.confirm():
-                return
-            STATS["select_fallbacks"] += 1
-            mod._rows_unfused_once = True                # some row's bound did not hold: this step again, unfused
-            raise _VoidAttempt()
-
-        pending = _settle_rows
+        S, pending = _fused_rows_select(c)
     fuse_jump = (FUSE_DENSE_JUMPRELU and bf16 and kind == "jumprelu" and isinstance(nl, (JumpReLU, ReLU)) and Bn % 8 == 0
                  and (L * F) % 4 == 0)
     # 16-bit regime of the JumpReLU module: the pre-activations (and later the feature gradient) leave their GEMMs as bf16 —
@@ -829,7 +1080,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
 
     spec = getattr(S, "speculated", None) if S is not None else None
     D = spec[0] if spec is not None else _Decoder(dec, shard, shadow=bool(sparse and bf16 and optimizer is not None))
-    N = Bn * L * d
+    N = c.N
     grads: Dict[str, torch.Tensor] = {}
     want_ys = kind == "topk"
 
@@ -888,32 +1139,7 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         # per layer, once its slab has been reduced: loss partial + gradient slab (+ bias-gradient row); called by the
         # backward pass right before the weight pass of W_l
         g = ys = None
-        if ex is not None:                               # split form: the loss ran on this rank's token block, per group
-            loss_parts, b_grad, g_lm = ex.loss_parts, ex.b_grad, ex.g_lm
-        else:
-            loss_parts = torch.zeros(L, dtype=torch.float64, device=dev)
-            b_grad = torch.empty(L, d, dtype=torch.float32, device=dev)
-            g_lm = torch.empty(L, Bn, d, dtype=ops.op16() if bf16 else torch.float32, device=dev)
-
-        group_of = {l: gi for gi, (lo, hi) in enumerate(groups) for l in range(lo, hi)}
-        done = set()
-
-        def slabs(l):
-            gi = group_of[l]
-            if gi not in done:                           # first layer of its group: wait for the group's all-reduce, then its loss
-                done.add(gi)
-                waits[gi]()                              # (the current stream waits; the host does not)
-                if ex is not None:                       # (... for the group's gathered gradient slabs: nothing left to compute)
-                    return g_lm[l]
-                lo, hi = groups[gi]
-                if not (bf16 and ops.mse_bf16_colsum_layers(r_lm[lo:hi], mlp_out[:, lo:hi], ost.mean[lo:hi], ost.std[lo:hi], N,
-                                                            g_lm[lo:hi], b_grad[lo:hi], loss_parts[gi:gi + 1])):
-                    for ll in range(lo, hi):             # generic form, layer by layer (fp32 mode, odd shapes)
-                        ls, gl, _ = ops.mse(r_lm[ll], mlp_out[:, ll], ost.mean[ll], ost.std[ll], True, False, count=N)
-                        loss_parts[gi:gi + 1].add_(ls)
-                        ops.column_sum(gl, b_grad[ll])
-                        g_lm[ll].copy_(ops.cast_bf16(gl) if bf16 else gl)
-            return g_lm[l]
+        slabs, loss_parts, b_grad = _group_slabs(c, groups, waits, ex, r_lm)
         if pending is not None:
             slabs(L - 1)                                 # (first group's loss kernel queued before the host read below)
         terms = {}
@@ -952,55 +1178,10 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         out.lazy["features"] = (lambda: ops.jumprelu_fwd(pre32(), theta)) if theta is not None else (lambda: ops.relu_fwd(pre32()))
 
     if lists_only:
-        S2 = g_aux = cx = None
+        S2 = g_aux = compact = None
         if kind == "topk":
-            aux = mod.topk_aux
-            if COMPACT_AUX and isinstance(aux, PerLayerTopK) and 0 < aux.k <= 2048:
-                cx = ops.compact_columns(dead)                      # one host read: the per-layer dead counts
-                if cx is not None and cx[0] > COMPACT_AUX_MAX_SHARE * F:
-                    cx = None
-                if cx is not None:
-                    # gathered weights (fp32 + bf16 + bf16 transposed) + their fp32 gradients + compact activations
-                    rows_c = sum(w.shape[0] for w in D.W32) * cx[0]
-                    need = rows_c * d * 12 + Bn * L * cx[0] * 16
-                    if need > 0.8 * torch.cuda.mem_get_info(dev)[0]:
-                        cx = None                                   # not enough HBM left: the activation-list form
-                if shard is not None:                               # both forms hold collectives: every rank takes the same one
-                    flag = torch.tensor([0 if cx is None else 1], dtype=torch.int32, device=dev)
-                    if int(shard.all_reduce_min(flag)) == 0:
-                        cx = None
-            if cx is not None:
-                # dense sub-problem on the dead columns: where(dead, pre, -inf) -> top k_aux -> relu restricted to them
-                n_pad, cidx, cmap = cx
-                # (16-bit modes: the dead columns' pre-activations come from the encoder GEMM on the gathered weight rows — same
-                # kernel, same bits — instead of a second read of `pre`: every 64-byte line of it holds a dead column or two)
-                if bf16 and F % 4 == 0 and d % 8 == 0 and Bn * n_pad >= 256 * 256 and COMPACT_AUX_GEMM_COLUMNS:
-                    pre_c = ops.encoder_fwd_columns(xo, enc.Wt, enc.b, cidx)
-                else:
-                    pre_c = ops.gather_cols(pre_acts(), cidx, float("-inf"))
-                if shard is None:
-                    feat_c = ops.topk_rows(pre_c, min(aux.k, n_pad))
-                else:               # k_aux of the dead features of ALL shards per row: exact global k-th value, then dense again
-                    Sc = ops.select_rows_sharded(pre_c, aux.k, shard, local_columns=True)
-                    feat_c = ops.sparse_scatter_dense(Sc, Sc.csc_val)
-                if bf16 and COMPACT_AUX_FUSED_OPERANDS and d % 4 == 0 and all(w.is_contiguous() for w in D.W32):
-                    # 16-bit operand forms of the dead rows straight from the decoder matrices (no gathered fp32 copies)
-                    Dc = _Decoder(_CompactDecoder(dec, [None] * len(D.W32), n_pad), shard, clt=D.clt)
-                    prepped = [ops.weight_prep_gather_bf16(w, cidx) for w in D.W32]
-                    Dc._Wop, Dc._WT = [p[0] for p in prepped], [p[1] for p in prepped]
-                else:
-                    Dc = _Decoder(_CompactDecoder(dec, [ops.gather_rows(w, cidx) for w in D.W32], n_pad), shard, clt=D.clt)
-                # 16-bit modes: both GEMM operand forms of the compact features (row-major for the forward, transposed for the
-                # weight gradient) from ONE read of them (the ReLU tile pass of the dense regime: feat_c >= 0 already)
-                fc16 = ops.jumprelu_fwd_bf16(feat_c, None)[:2] if (bf16 and COMPACT_AUX_FUSED_OPERANDS and Bn % 8 == 0) else None
-                aux_r = Dc.fwd(feat_c, feat_op=fc16[0] if fc16 is not None else None)
-            else:
-                S2 = _select_lists(aux, pre_acts(), dead, shard)
-                aux_r = D.sparse_fwd(S2)
-            aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
-            terms["aux"] = (aux_sum[0] / N).float()
+            S2, g_aux, compact = _aux_forward_lists(c, D, dead, pre_acts, ys, r, g, terms, grads)
             loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
-            grads["decoder.b"] = ops.column_sum(g_aux)
         else:
             loss = terms.get("mse")              # (pipelined exchange: known after the backward pass)
         if b_grad is not None:
@@ -1009,23 +1190,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
         xsrc = xs16 if bf16 else xs32
         extra_dec = extra_enc = None
-        if cx is not None:
-            gc: Dict[str, torch.Tensor] = {}
-            Dc.wgrad(feat_c, g_aux, gc, featT=fc16[1] if fc16 is not None else None)
-            if fc16 is not None:
-                # masked feature gradient straight to the transposed 16-bit operand + its column sums (no fp32 dpre tensor)
-                dT_c, db_c = ops.mask_positive_t(feat_c, Dc.dgrad(g_aux))
-            else:
-                dpre_c = ops.mask_positive(feat_c, Dc.dgrad(g_aux))
-                dT_c = ops.transpose_cast_2d(dpre_c).view(L, n_pad, Bn) if bf16 else None
-                db_c = ops.column_sum(dpre_c)
-            if bf16:
-                dWt_c = torch.empty(L, n_pad, d, dtype=torch.float32, device=dev)
-                ops.wgrad_t(dT_c, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt_c, L, n_pad * Bn, d * Bn)
-            else:
-                dWt_c = ops.encoder_wgrad(xs32, dpre_c)
-            extra_dec = (gc, cmap)
-            extra_enc = (dWt_c.view(-1, d), cmap, db_c.view(-1))
+        if compact is not None:
+            extra_dec, extra_enc = _aux_compact_backward(c, compact, g_aux)
         if fp16:                                  # every rank takes the same skip decision in the Adam-carrying row passes
             agree_on_overflow(shard, flag)
         dval, dval2 = D.sparse_bwd(S, g, S2, g_aux if S2 is not None else None, grads, optimizer, extra=extra_dec, g16=g16,
@@ -1037,95 +1203,19 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
             loss = terms["mse"]
             late_dead[1]()
             terms["dead_fraction"] = late_dead[0][0].float() / (L * F * shard.world)
-        # encoder: dpre is non-zero only at the list entries (scatter(relu(gather)) backward), so the weight
-        # gradient of feature (l,i) is sum_p dval[p] * xs[tok[p], l, :] and its bias gradient sum_p dval[p]
-        db = torch.empty(L, F, dtype=torch.float32, device=dev)
-        Wt = enc.Wt
-        kw = dict(colsum=db, second=(S2, dval2, xsrc) if S2 is not None else None, extra=extra_enc)
-        if optimizer is not None:
-            kw.update(optimizer.begin_fused(enc.W, storage=Wt))
-            if bf16:
-                kw["shadow"] = _encoder_operand(enc)
-        else:
-            dWt = torch.empty_like(Wt)
-            kw["grad_out"] = dWt
-            grads["encoder.W"] = dWt.permute(0, 2, 1)
-        ops.sparse_row_pass(Wt, S, dval, xsrc, 0, -1, **kw)
-        grads["encoder.b"] = db
+        _encoder_pass_lists(c, S, dval, S2, dval2, xsrc, extra_enc, grads)
         out["lists"] = S
         terms["loss"] = loss
         out["loss"] = loss
         return out
 
     if kind == "jumprelu":
-        if not isinstance(nl, (JumpReLU, ReLU)):
-            raise NotImplementedError("JumpReLU loss module needs a JumpReLU/ReLU nonlinearity in the fused step")
-        lam = mod._lambda * (mod.global_step / mod.trainer.max_steps)
-        th = theta if theta is not None else torch.zeros(1, L, F, device=pre.device)
-        bw = nl._bandwidth if theta is not None else 1.0
-        sq = D.sqnorms()
-        g16 = ops.cast_bf16(g) if (bf16 and S is not None) else None
-        loss16 = fused_ops is not None or (S is not None and fuse_jump)
-        dfeat = D.dgrad(g, go=g16, out_bf16=bool(loss16 and DENSE_BF16_ACTIVATIONS))
-        if loss16:
-            sums, dpreT, db, dth, dn = ops.jumprelu_loss_bwd_bf16(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
-                                                                  mod.pre_actv_loss / (Bn * L), bias=pre_bias)
-        else:
-            sums, dpre, dth, dn = ops.jumprelu_loss_bwd(pre, th, sq, dfeat, bw, lam / Bn, mod.c, mod.use_tanh,
-                                                        mod.pre_actv_loss / (Bn * L))
-        if shard is not None:                 # loss terms are sums over the feature axis (gradients stay local)
-            sums = shard.all_reduce_sum(sums.clone())
-            if fp16:                          # d(pre) is per shard: every rank must take the same skip decision
-                agree_on_overflow(shard, flag)
-        if S is not None:
-            # list regime: dW_l[l', i, :] = sum over the tokens where feature (l', i) is active of val * g[tok, l, :], plus the
-            # row's dec_norms term — one streaming pass per decoder matrix, Adam applied in it when an optimizer is handed in
-            D.sparse_wgrad(S, g, grads, optimizer, (dn, sq), g16)
-            out["lists"] = S
-        else:
-            D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
-            D.add_norm_grads(dn, sq, grads, optimizer)
-        grads["decoder.b"] = ops.column_sum(g)
-        if theta is not None:
-            grads["nonlinearity.theta"] = dth
-        terms["sparsity"] = (lam * sums[0] / Bn).float()
-        terms["pre_actv"] = (mod.pre_actv_loss * sums[1] / (Bn * L)).float()
-        terms["weighted_features_mean"] = (sums[2] / (Bn * L * F * (shard.world if shard is not None else 1))).float()
-        terms["sparsity_penalty"] = torch.tensor(lam)
-        loss = terms["mse"] + terms["sparsity"] + terms["pre_actv"]
+        loss, dpre, dpreT, db = _backward_jumprelu(c, D, S, pre, pre_bias, theta, feat, fused_ops, fuse_jump, g, terms, grads, out)
     else:
-        if kind == "topk":
-            aux = mod.topk_aux
-            dead_pre = ops.mask_dead(pre, dead)
-            dead_feat = _select(aux, dead_pre)
-            aux_r = D.fwd(dead_feat)
-            aux_sum, g_aux = ops.aux_mse(aux_r, ys, r, g, mod.aux_loss_scale)      # g += g_aux in place
-            terms["aux"] = (aux_sum[0] / N).float()
-            loss = terms["mse"] + mod.aux_loss_scale * terms["aux"]
-            D.wgrad(dead_feat, g_aux, grads)
-            grads["decoder.b"] = ops.column_sum(g_aux)
-        else:
-            loss = terms["mse"]
-        D.wgrad(feat, g, grads)
-        grads["decoder.b"] = ops.column_sum(g, grads.get("decoder.b"), accumulate="decoder.b" in grads)
-        dfeat = D.dgrad(g)
-        if theta is not None:
-            dpre, grads["nonlinearity.theta"] = ops.jumprelu_bwd(pre, theta, nl._bandwidth, dfeat)
-        elif isinstance(nl, ReLU):
-            dpre = ops.relu_bwd(pre, dfeat)
-        else:
-            dpre = ops.mask_positive(feat, dfeat)
-        if kind == "topk":
-            ops.mask_positive(dead_feat, D.dgrad(g_aux), out=dpre, accumulate=True)   # aux path reaches dead entries only
+        loss, dpre = _backward_dense(c, D, pre, feat, theta, dead, ys, r, g, terms, grads)
+        dpreT = db = None
 
-    if bf16:       # dWt[l] [F, d] = dpre[:, l]^T @ xs[:, l], contraction over tokens: both operands token-minor
-        dWt = torch.empty(L, F, d, dtype=torch.float32, device=pre.device)
-        dT = dpreT if dpreT is not None else ops.transpose_cast_2d(dpre).view(L, F, Bn)
-        ops.wgrad_t(dT, ops.transpose_cast_2d(xs32).view(L, d, Bn), dWt, L, F * Bn, d * Bn)
-        grads["encoder.W"] = dWt.permute(0, 2, 1)
-    else:
-        grads["encoder.W"] = ops.encoder_wgrad(xo, dpre).permute(0, 2, 1)
-    grads["encoder.b"] = db if dpreT is not None else ops.column_sum(dpre)
+    _encoder_wgrad_dense(c, pre, dpre, dpreT, db, grads)
     if optimizer is not None:
         D.register_prep(optimizer, enc)
     terms["loss"] = loss

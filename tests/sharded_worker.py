@@ -240,7 +240,7 @@ def gpu_exchange_forms(rank, world):
             assert_close(p1[k], p0[k], 1e-4, 0.3 * 1e-3, f"{prec} param {k}")
 
 
-def gpu_fp16_overflow_on_one_shard(rank, world):
+def gpu_fp16_overflow_on_one_shard(rank, world, nonlinearity={"kind": "batchtopk", "k": 8, "e": 0.1}, loss={"kind": "base"}):
     """`precision: "16-mixed"` under feature sharding: an fp16 overflow that only ONE rank's shard produces (a decoder weight
     too large for fp16 in the last rank's slice: the 16-bit shadow cast raises that rank's flag) must skip the step on EVERY
     rank — same loss scale, same skip count, untouched parameters and optimizer state, replicated decoder.b still identical —
@@ -255,8 +255,8 @@ def gpu_fp16_overflow_on_one_shard(rank, world):
               "decoder.b": torch.zeros(L, d)}
     for l in range(L):
         params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
-    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "batchtopk", "k": 8, "e": 0.1},
-                    "loss": {"kind": "base"}}, "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": nonlinearity, "loss": loss},
+            "opt": {"lr": 1e-3}, "batches": torch.stack(batches),
             "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 10}
     mod = build_module(case, "cuda:0")
     shard = FeatureShard(F, keep_single=KEEP_SINGLE)
@@ -563,6 +563,10 @@ def main():
             gpu_bf16_fused_sharded(rank, world)
             gpu_exchange_forms(rank, world)
             gpu_fp16_overflow_on_one_shard(rank, world)
+            # ... and under the TopK-aux module, whose list regime holds a second agreement (compact or list form of the aux pass)
+            gpu_fp16_overflow_on_one_shard(rank, world, {"kind": "topk", "k": 8},
+                                           {"kind": "topk", "topk_aux": {"kind": "topk", "k": 32}, "tokens_till_dead": 512,
+                                            "aux_loss_scale": 0.1})
             gpu_save_sharded(rank, world)
             from crosslayer_transcoder_amd import engine
             for name in args.cases.split(","):
