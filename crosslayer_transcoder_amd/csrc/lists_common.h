@@ -291,7 +291,7 @@ __global__ __launch_bounds__(1024) void scan_chunks_kernel(const uint32_t* __res
 // scratch == nullptr or a short array: the single-workgroup kernel
 static inline void launch_scan(const uint32_t* cnt, int n, uint32_t* start, uint32_t* total, uint8_t* fired, const int32_t* gate,
                                int gate_on, uint32_t* scratch, hipStream_t st) {
-    if (!scratch || n <= 65536) {
+    if (!scratch || n <= 8192) {              // (49152 items: one workgroup 21 us, twelve chunks 5 + 5 us)
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n, start, total, fired, gate, gate_on);
         return;
     }

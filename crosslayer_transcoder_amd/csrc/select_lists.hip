@@ -540,7 +540,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             const int rc = clt_internal_topk_rows(a.x, nullptr, rows, F, k, ci, sval, a.col_mask, L, row_cnt, col_cnt, st,
                                                   w8 + p.off_fbsel, p.off_fbbuild - p.off_fbsel);
             if (rc != CLT_OK) return rc;
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            launch_scan(row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, ci, sval, k, F, L, rows, a.row_start, a.cap,
                                a.ent_col, a.ent_val, a.overflow);
         } else if (stage == 1) {
@@ -567,7 +567,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;
             hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
                                sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, tiex);
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            launch_scan(row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);
             launch_sort_rows(st, a.row_start, rows, a.ent_col, a.ent_val, long_list, &head->long_rows, gate, 0);
@@ -602,7 +602,7 @@ int run_stages(const SelArgs& a, int lo, int hi) {
             const uint32_t capsel = a.cap < kall ? a.cap : (uint32_t)kall;          // sel_idx / sel_val hold K entries
             hipLaunchKernelGGL(emit_kernel, cgrid, dim3(TPB), 0, st, ckey, cidx, p.capS, ctl, state, tie_region, p.S, a.sd, F, L, capsel,
                                sidx, sval, row_cnt, col_cnt, a.threshold, a.ema_e, head, a.overflow, local_radix ? tiex : (const TieX*)nullptr);
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0);
+            launch_scan(row_cnt, rows, a.row_start, a.total, (uint8_t*)nullptr, gate, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(512), dim3(TPB), 0, st, sidx, sval, head, capsel, F, L, a.row_start, row_cur,
                                a.ent_col, a.ent_val);
             launch_sort_rows(st, a.row_start, rows, a.ent_col, a.ent_val, long_list, &head->long_rows, gate, 0);
@@ -762,7 +762,7 @@ int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int 
             const int rc = clt_internal_topk_merge_slots((const uint32_t*)(w8 + p.off_skey), (const int32_t*)(w8 + p.off_sslot), slot_cnt, slots, k,
                                                          F, L, rows, sidx, sval, row_cnt, col_cnt, gate, st);
             if (rc != CLT_OK) return rc;
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, (const int32_t*)nullptr, 0);
+            launch_scan(row_cnt, rows, row_start, total, (uint8_t*)nullptr, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, sidx, sval, k, F, L, rows, row_start, cap, ent_col,
                                ent_val, overflow);
             launch_scan(col_cnt, ncols, col_start, nullptr, fired, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);

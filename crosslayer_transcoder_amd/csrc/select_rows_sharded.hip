@@ -210,8 +210,7 @@ int clt_select_rows_sharded_f32(int stage_lo, int stage_hi, int world, int rank,
         } else {
             hipLaunchKernelGGL(rows_apply_kernel, wgrid, dim3(TPB), 0, st, cidx, cval, row_cnt, p.kk, rows, F, L, state, ties, world,
                                rank, col_cnt);
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr,
-                               (const int32_t*)nullptr, 0);
+            launch_scan(row_cnt, rows, row_start, total, (uint8_t*)nullptr, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(compact_rows_kernel, wgrid, dim3(TPB), 0, st, cidx, cval, p.kk, F, L, rows, row_start, cap, ent_col,
                                ent_val, overflow);
             launch_scan(col_cnt, ncols, col_start, nullptr, fired, nullptr, 0, (uint32_t*)long_list, st);   // (long_list idle until sort_cols)

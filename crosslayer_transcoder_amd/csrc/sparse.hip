@@ -899,7 +899,7 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
     if (xt == 0) hipLaunchKernelGGL((count_rows_kernel<0>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     else if (xt == 1) hipLaunchKernelGGL((count_rows_kernel<1>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
     else hipLaunchKernelGGL((count_rows_kernel<2>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_cnt, gate, 1, wave_cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1);
+    launch_scan(row_cnt, rows, row_start, total, (uint8_t*)nullptr, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
     if (own_gate) {         // (threshold lists: the remaining kernels exit at once when the count exceeds cap)
         int32_t* gw = (int32_t*)(long_count + 8);
         hipLaunchKernelGGL(list_gate_kernel, dim3(1), dim3(1), 0, st, total, cap, gw, overflow);
