@@ -529,11 +529,14 @@ __global__ __launch_bounds__(LTPB) void sort_long_cols_kernel(const uint32_t* __
     __shared__ int32_t mine[LTPB];
     __shared__ uint32_t nmine;
     const uint32_t nl = *long_count;
-    for (uint32_t base = blockIdx.x * LTPB; base < nl; base += gridDim.x * LTPB) {
+    // (block b reads the queue entries congruent to b modulo the grid: hot columns are neighbours in the queue — a Zipf
+    // dictionary's frequent features have neighbouring indices — and one block must not end up with all of them)
+    for (uint32_t base = 0; base < nl; base += gridDim.x * LTPB) {
         if (threadIdx.x == 0) nmine = 0;
         __syncthreads();
-        if (base + threadIdx.x < nl) {
-            const int c = long_list[base + threadIdx.x];
+        const uint32_t q = base + threadIdx.x * gridDim.x + blockIdx.x;
+        if (q < nl) {
+            const int c = long_list[q];
             const uint32_t n = col_start[c + 1] - col_start[c];
             if (n > MIDCOL_MAX && n <= LONGCOL_MAX) mine[atomicAdd(&nmine, 1u)] = c;    // (beyond LONGCOL_MAX: left in arrival
         }                                                                               //  order — still correct, not bit-reproducible)
@@ -574,7 +577,7 @@ static inline void launch_sort_rows(hipStream_t st, const uint32_t* row_start, i
                                     uint32_t* long_count, const int32_t* gate, int gate_on) {
     hipLaunchKernelGGL(sort_rows_kernel, dim3((rows + LTPB / 64 - 1) / (LTPB / 64)), dim3(LTPB), 0, st, row_start, rows, col, val, long_list,
                        long_count, gate, gate_on);
-    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(LTPB), 0, st, row_start, col, val, (int32_t*)nullptr, long_list, long_count,
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(LTPB), 0, st, row_start, col, val, (int32_t*)nullptr, long_list, long_count,
                        gate, gate_on);
 }
 
@@ -582,7 +585,7 @@ static inline void launch_sort_rows(hipStream_t st, const uint32_t* row_start, i
 static inline void launch_sort_queued_cols(hipStream_t st, const uint32_t* col_start, int32_t* tok, float* val, int32_t* ent,
                                            const int32_t* long_list, const uint32_t* long_count, const int32_t* gate, int gate_on) {
     hipLaunchKernelGGL(sort_mid_cols_kernel, dim3(2048), dim3(LTPB), 0, st, col_start, tok, val, ent, long_list, long_count, gate, gate_on);
-    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(256), dim3(LTPB), 0, st, col_start, tok, val, ent, long_list, long_count, gate, gate_on);
+    hipLaunchKernelGGL(sort_long_cols_kernel, dim3(512), dim3(LTPB), 0, st, col_start, tok, val, ent, long_list, long_count, gate, gate_on);
 }
 
 
