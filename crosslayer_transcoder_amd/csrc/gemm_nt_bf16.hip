@@ -582,6 +582,9 @@ int gemm_diag() {
 // per-lane DMA offsets are 32-bit byte offsets from the tile's first row (+ the k offset in the scalar offset)
 bool dma_offsets_fit(long lda, long ldb, long K) { return (255 * (lda > ldb ? lda : ldb) + K) * 2 < 0x7fffffffL; }
 
+// > 0: the persistent grid takes at most this many blocks (a multiple of 8): a launch that leaves the other CUs to a
+// bandwidth-bound kernel running beside it on another stream (clt_gemm_nt_grid_limit)
+int g_grid_limit = 0;
 // persistent grid: one block per CU (a multiple of 8, so that a block keeps its XCD over all its tiles)
 int persistent_grid(long nblk) {
     static int cus = 0;
@@ -590,7 +593,8 @@ int persistent_grid(long nblk) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) cus = 256;
         else cus = pr.multiProcessorCount >= 8 ? pr.multiProcessorCount / 8 * 8 : 8;
     }
-    return (int)(nblk < cus ? nblk : cus);
+    const int lim = g_grid_limit > 0 && g_grid_limit < cus ? g_grid_limit : cus;
+    return (int)(nblk < lim ? nblk : lim);
 }
 // which form of the kernel the store epilogues launch: 1 = every wave loads and stores (rounds 1-2), 2 = loader / storer
 // waves, 0 = by shape: the loader / storer form for 2048 <= K <= 8192 (measured, profiles/r03_gemm_ab.md: 8192^3 1372 ->
@@ -604,6 +608,13 @@ extern "C" int clt_gemm_nt_variant(int variant, int reserved) {
     const int old = g_nt_variant;
     if (variant >= 0 && variant <= 2) g_nt_variant = variant;
     (void)reserved;
+    return old;
+}
+
+// see include/clt_hip.h
+extern "C" int clt_gemm_nt_grid_limit(int blocks) {
+    const int old = g_grid_limit;
+    if (blocks >= 0) g_grid_limit = blocks / 8 * 8;
     return old;
 }
 
