@@ -98,7 +98,7 @@ SIGNATURES = {
                                           C.c_double, I, I, I, P, P, C.c_uint32, I, C.c_uint32, P, P]),
     "clt_sparse_row_pass_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, L, L, I, P,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, I, P, P, P, P, P, P,
-                                    P, P, C.c_uint32, I, C.c_uint32, P, P]),
+                                    P, P, C.c_uint32, I, C.c_uint32, P, I, P]),
     "clt_sparse_hot_columns": (I, [P, I, I, P, C.c_uint32, C.c_uint32, P, P]),
     "clt_compact_columns": (I, [P, I, I, I, P, P, P, P]),
     "clt_gather_cols_f32": (I, [P, P, I, I, I, I, F32, P, P]),
@@ -109,7 +109,7 @@ SIGNATURES = {
     "clt_adam_prep_f32": (I, [P, P, P, P, I, I, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, P, P, P]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class CltError(RuntimeError):

@@ -999,9 +999,10 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double beta1, double beta2, double eps, double weight_decay, int adamw, int step, int src_bf16,
                             const float* extra, const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm,
                             const float* row_sq, float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap,
-                            int hot_min_len, uint32_t hot_seg_cap, float* hot_partials, void* stp) {
+                            int hot_min_len, uint32_t hot_seg_cap, float* hot_partials, int hot_phase, void* stp) {
     if (rows <= 0 || d <= 0 || F <= 0 || L <= 0) return CLT_ERR_SHAPE;
     if (hot_list && (!hot_count || hot_cap == 0 || hot_min_len < 1)) return CLT_ERR_SHAPE;
+    if (hot_phase < 0 || hot_phase > 2 || (hot_phase && !hot_list)) return CLT_ERR_SHAPE;
     if ((row_dnorm != nullptr) != (row_sq != nullptr)) return CLT_ERR_SHAPE;
     if (sq_out && (grad_out || d > 1024)) return CLT_ERR_SHAPE;   // the updated row's norm: Adam form, one wave per row
     if (!grad_out && (!m || !v || step < 1)) return CLT_ERR_SHAPE;
@@ -1026,6 +1027,10 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
     const dim3 g4((rows + 3) / 4), g1(rows);
     const bool hot = hot_list && vec && chunks <= 4;          // (one wave per row with 16-byte lanes: the hot-row form applies)
     a.hot_min_len = hot ? hot_min_len : 0;
+    // hot_phase 1 / 2: the common launch alone / the hot rows' launches alone — the caller runs the two on different streams (they
+    // touch disjoint rows and dot slots).  A shape the hot-row form does not apply to has no hot phase: everything is phase 1
+    if (hot_phase == 2 && !hot) return CLT_OK;
+    const bool common = hot_phase != 2, hot_rows = hot && hot_phase != 1;
 #define RP(NT_, VEC_, CW_, GRID_)                                                                                          \
     do {                                                                                                                    \
         if (CW_ == 1 && sq_out) {                                                                                           \
@@ -1034,7 +1039,8 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
         } else if (clt_host_state.fp16) hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_, true>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a); \
         else hipLaunchKernelGGL((row_pass_kernel<NT_, VEC_, CW_>), GRID_, dim3(CW_ == 1 ? TPB : 64 * CW_), 0, st, a);       \
     } while (0)
-    if (vec) {
+    if (!common) {
+    } else if (vec) {
         if (chunks <= 1) RP(1, true, 1, g4);
         else if (chunks <= 2) RP(2, true, 1, g4);
         else if (chunks <= 3) RP(3, true, 1, g4);
@@ -1052,7 +1058,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
         else return CLT_ERR_RANGE;
     }
 #undef RP
-    if (hot) {
+    if (hot_rows) {
         RowPassGroup none = {};
 #define RPH(NT_)                                                                                                          \
     do {                                                                                                                    \

@@ -103,6 +103,9 @@ ROW_PASS_SMALL = 50_000_000          # mean parameters per decoder matrix below 
 #: short passes of one layer group in one launch (CLT_AB=group_row_passes=0: off, for A/B runs)
 GROUP_ROW_PASSES = bool(ab_switch("group_row_passes", 1))
 _side_stream = ops._side_stream          # (one side stream per device, shared with ops.clt_decoder_dgrad_kseg)
+#: heavy-tailed lists: the hot rows' launches of a weight pass (segments + rows, ~0.1 ms of short latency-bound work per matrix)
+#: run on a stream of their own under the common launch instead of behind it (CLT_AB=hot_rows_stream=0: behind it, for A/B runs)
+HOT_ROWS_STREAM = bool(ab_switch("hot_rows_stream", 1))
 #: TopK-aux pass (k_aux of the DEAD features per row, second decoder pass) as a dense sub-problem on compacted dead
 #: columns (csrc/compact.hip) instead of activation lists, as long as the dead columns are at most this share of F
 COMPACT_AUX = True
@@ -164,6 +167,41 @@ def _encoder_operand(enc):
             sh = ops.cast_bf16(Wt)
             enc._bf16_shadow, enc._shadow_version = sh, ver
     return sh
+
+
+_hot_streams = {}
+
+
+class _HotFork:
+    """Weight passes whose hot rows run on a second stream (ops.sparse_row_pass hot_phase 1 / 2: disjoint rows and dot slots).
+    Created AFTER everything the passes write has been allocated and the optimizer state exists (a buffer allocated or zero-
+    filled on the launch stream after the fork is not ordered against the second stream); join() before anything reads the
+    passes' results.  Off without hot columns, under bench.py's per-launch timing, and when not asked for."""
+
+    def __init__(self, S, dev, enabled=True):
+        self.on = bool(enabled and HOT_ROWS_STREAM and ops.TIMING is None and ops.hot_columns(S) is not None)
+        if self.on:
+            key = torch.device(dev).index or 0
+            if key not in _hot_streams:
+                _hot_streams[key] = torch.cuda.Stream(device=dev)
+            self.main, self.side = torch.cuda.current_stream(dev), _hot_streams[key]
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.side.wait_event(ev)
+
+    def row_pass(self, *args, **kw):
+        if not self.on:
+            return ops.sparse_row_pass(*args, **kw)
+        ops.sparse_row_pass(*args, hot_phase=1, **kw)
+        with torch.cuda.stream(self.side):
+            ops.sparse_row_pass(*args, hot_phase=2, **kw)
+
+    def join(self):
+        if self.on:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+            self.on = False
 
 
 class _CompactDecoder:
@@ -376,20 +414,25 @@ class _Decoder:
         if self.bf16:
             g = g16 if g16 is not None else ops.cast_bf16(g)
         keep = ROW_PASS_KEEPS_NORMS and fused is not None and self.dec.d_acts <= 1024
-        parts = []
         self.dec._row_sq_parts = None
-        for l, (name, w) in enumerate(zip(self.names(), self.W32)):
+        todo = list(zip(self.names(), self.W32))
+        # (optimizer state and the kept-norm buffers exist before the hot rows' stream forks off)
+        begun = [fused.begin_fused(w) for _, w in todo] if fused is not None else None
+        parts = [torch.empty(w.numel() // w.shape[-1], dtype=torch.float32, device=w.device) for _, w in todo] if keep else []
+        ops.hot_columns(S)
+        fork = _HotFork(S, g.device, enabled=fused is not None)
+        for l, (name, w) in enumerate(todo):
             kw = dict(row_term=row_term)
             if fused is not None:
-                kw.update(fused.begin_fused(w))
+                kw.update(begun[l])
                 if self.shadow:
                     kw["shadow"] = self.shadows()[l]
                 if keep:
-                    parts.append(torch.empty(w.numel() // w.shape[-1], dtype=torch.float32, device=w.device))
-                    kw["sq_out"] = parts[-1]
+                    kw["sq_out"] = parts[l]
             else:
                 grads[name] = kw["grad_out"] = torch.empty_like(w)
-            ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+            fork.row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+        fork.join()
         if keep:                                # valid while nothing else changes the weights (same key as the shadows)
             self.dec._row_sq_parts = (self._version_key(), parts)
 
@@ -440,11 +483,15 @@ class _Decoder:
         else:
             begun = None
         two = ROW_PASS_STREAMS > 1 and small and ops.TIMING is None and len(todo) > 1
-        if two and fused is not None and begun is None:
+        hot_fork = fused is not None and slabs is None and not two
+        if (two or hot_fork) and fused is not None and begun is None:
             # the optimizer creates (zero-fills) a matrix's moment buffers in begin_fused on its first step: all of them on this
             # stream BEFORE the side stream's wait point below — created inside the loop, a side-stream pass raced its own
             # matrix's zero fill (first step only; found by the heavy-tail test of round 3)
             begun = {l: fused.begin_fused(w) for l, (_, w) in todo}
+        if hot_fork and self.shadow:
+            self.shadows()                       # (cast on the launch stream before the fork, when they do not exist yet)
+        fork = _HotFork(S, dev, enabled=hot_fork)
         if two:
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             ev = torch.cuda.Event()
@@ -471,7 +518,8 @@ class _Decoder:
                 with torch.cuda.stream(side):
                     ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
             else:
-                ops.sparse_row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+                fork.row_pass(w, S, S.csc_val, g, 0, l if self.clt else -1, **kw)
+        fork.join()
         if two:
             ev = torch.cuda.Event()
             ev.record(side)
@@ -741,7 +789,9 @@ def _encoder_pass_lists(c, S, dval, S2, dval2, xsrc, extra_enc, grads):
         dWt = torch.empty_like(Wt)
         kw["grad_out"] = dWt
         grads["encoder.W"] = dWt.permute(0, 2, 1)
-    ops.sparse_row_pass(Wt, S, dval, xsrc, 0, -1, **kw)
+    fork = _HotFork(S, dev, enabled=optimizer is not None and c.shard is None)
+    fork.row_pass(Wt, S, dval, xsrc, 0, -1, **kw)
+    fork.join()
     grads["encoder.b"] = db
 
 

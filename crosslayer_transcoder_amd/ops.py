@@ -1404,7 +1404,7 @@ def _hot_args(s, d: int = 0, nmat: int = 1):
 
 def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, grad_out=None, adam=None, m=None, v=None,
                     shadow=None, dots=None, dot_slot=0, colsum=None, second=None, dots2=None, extra=None, row_term=None,
-                    src_slab=False, sq_out=None):
+                    src_slab=False, sq_out=None, hot_phase=0):
     """See clt_sparse_row_pass_f32.  W: contiguous [..., d] weight rows.  `adam` = dict(lr, beta1, beta2, eps,
     weight_decay, adamw, step) for the in-place update, or grad_out for the gradient only.
     `second` = (lists2, coef2, src2): an additional (CSC list, coefficient, source) contribution whose
@@ -1412,7 +1412,13 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
     compact colsum or None): dense contribution of the compacted TopK-aux pass for the mapped rows.
     `row_term` = (dnorm [L*F], sq [L*F]): adds (dnorm[col] / sqrt(sq[col])) * W[row] to the row's gradient.
     `src_slab`: `src` is ONE layer's slab [B, d] (layer `src_layer` of a layer-major source) instead of [B, L, d].
-    `sq_out` ([rows] fp32; Adam form, d <= 1024): squared length of every UPDATED row (= row_sqnorm of the new matrix)."""
+    `sq_out` ([rows] fp32; Adam form, d <= 1024): squared length of every UPDATED row (= row_sqnorm of the new matrix).
+    `hot_phase`: 1 = the common launch alone, 2 = the hot rows' launches alone (for a caller that queues the two on different
+    streams, engine.HOT_ROWS_STREAM); without a hot-column list phase 1 is the whole pass and phase 2 nothing."""
+    if hot_phase and hot_columns(s) is None:
+        if hot_phase == 2:
+            return
+        hot_phase = 0
     _chk(W); _chk(coef)
     if sq_out is not None:
         _chk(sq_out)
@@ -1445,7 +1451,8 @@ def sparse_row_pass(W, s: SparseLists, coef, src, col0: int, src_layer: int, *, 
          ptr(s2.col_start) if s2 is not None else None, ptr(s2.csc_tok) if s2 is not None else None, ptr(c2), ptr(x2),
          ptr(dots), ptr(dots2), s.cap, s2.cap if s2 is not None else 0, dot_slot, ptr(colsum), float(a["lr"]),
          float(a["beta1"]), float(a["beta2"]), float(a["eps"]), float(a["weight_decay"]), int(a["adamw"]),
-         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), ptr(sq_out), *_hot_args(s, d), _stream())
+         int(a["step"]), int(src_bf16), ptr(ex), ptr(exmap), ptr(excs), ptr(rdn), ptr(rsq), ptr(sq_out), *_hot_args(s, d), int(hot_phase),
+         _stream())
 
 
 def sparse_row_pass_group(Ws, s: SparseLists, coef, srcs, layers, *, adam, ms, vs, shadows=None, dots=None, src_slab=False) -> bool:

@@ -462,7 +462,11 @@ int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col
  * floats — times nmat for the group form; not to be shared by launches that may run concurrently) every segment is walked by
  * a block of its own and the row's wave adds the segments' sums in segment order: equal work items whatever the column
  * lengths (a feature that fires in half of the tokens — 2000 entries — no longer keeps one block busy while the chip waits).
- * Without hot_partials a hot row is walked by one wave of the second launch. */
+ * Without hot_partials a hot row is walked by one wave of the second launch.
+ * hot_phase (clt_sparse_row_pass_f32; needs hot_list): 0 = all launches on `stream`; 1 = the common launch alone; 2 = the hot
+ * rows' launches alone (nothing when the hot-row form does not apply to the shape: phase 1 then covers every row).  The two
+ * phases touch disjoint rows and dot slots, so a caller may queue them on two streams and let the short, latency-bound hot
+ * launches run under the common pass instead of behind it. */
 int clt_sparse_hot_columns(const uint32_t* col_start, int ncols, int min_len, int32_t* hot_list, uint32_t hot_cap,
                            uint32_t seg_cap, uint32_t* hot_count, void* stream);
 int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, float* grad_out, int rows, int d, int F,
@@ -473,7 +477,7 @@ int clt_sparse_row_pass_f32(float* W, float* m, float* v, uint16_t* shadow, floa
                             double weight_decay, int adamw, int step, int src_bf16, const float* extra,
                             const int32_t* extra_map, const float* extra_colsum, const float* row_dnorm, const float* row_sq,
                             float* sq_out, const int32_t* hot_list, const uint32_t* hot_count, uint32_t hot_cap, int hot_min_len,
-                            uint32_t hot_seg_cap, float* hot_partials, void* stream);
+                            uint32_t hot_seg_cap, float* hot_partials, int hot_phase, void* stream);
 /* Several weight matrices of one decoder in ONE launch of the same pass (Adam in place; no gradient output, second list,
  * compact contribution or row term): matrix i has rows[i] rows of d floats (row r <-> CSC column r), gathers from src[i]
  * (a [B][L][d] tensor, layer src_layer[i]; fp32, or 16-bit when src_bf16) and writes its dots to slot

@@ -72,7 +72,7 @@ def main():
 
     def run_rows(stream):
         for a in rows:
-            orig_call("clt_sparse_row_pass_f32", *a[:-1], stream.cuda_stream)
+            orig_call("clt_sparse_row_pass_f32", *a[:-1], stream.cuda_stream)      # (the stream is the last argument)
 
     def run_gemm(stream, limit):
         _lib.lib.clt_gemm_nt_grid_limit(limit)
