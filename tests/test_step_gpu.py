@@ -646,6 +646,45 @@ def test_debug_yaml_config_end_to_end(tmp_path, golden):
 
 
 @pytest.mark.parametrize("prec", ["32", "bf16-mixed"])
+def test_hot_rows_on_their_own_stream_give_the_same_bits(prec, monkeypatch):
+    """engine.HOT_ROWS_STREAM: the hot rows' launches of every weight pass queued on a second stream (hot_phase 1 / 2 of
+    clt_sparse_row_pass_f32) touch rows and dot slots of their own — three fused Adam steps leave every parameter and moment
+    bit-identical to the one-stream order."""
+    from crosslayer_transcoder_amd import engine, ops, precision
+    from tests.build_cases import build_module
+    B, L, d, F, k = 768, 3, 128, 512, 8
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, L, d, generator=g)
+    y = 0.5 * x * torch.randn(L, d, generator=g) + 0.1 * torch.randn(B, L, d, generator=g)
+    batch = torch.stack([x, y], 1)
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
+              "decoder.b": torch.randn(L, d, generator=g) * 0.01}
+    params["encoder.b"][:, 5::97] = 0.9
+    for l in range(L):
+        params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "batchtopk", "k": k, "e": 0.1}, "loss": {"kind": "base"}},
+            "opt": {"lr": 1e-3}, "batches": batch[None], "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long),
+            "max_steps": 10}
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(engine, "HOT_ROWS_STREAM", on)
+        mod = build_module(case)
+        mod.log_metrics_every = 0
+        opt, _ = mod.attach_optimizers()
+        with precision(prec):
+            for t in range(3):
+                mod.fused_train_step(batch.cuda(), t, opt)
+        S = mod.last_step["lists"]
+        assert ops.hot_columns(S) is not None and int((S.col_start[1:] - S.col_start[:-1]).max()) > 256
+        torch.cuda.synchronize()
+        res[on] = {k_: (p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                   for k_, p in mod.model.named_parameters()}
+    for k_ in res[True]:
+        for a, b in zip(res[True][k_], res[False][k_]):
+            assert torch.equal(a, b), k_
+
+
+@pytest.mark.parametrize("prec", ["32", "bf16-mixed"])
 @pytest.mark.parametrize("kind", ["batchtopk", "topk-aux-lists"])
 def test_heavy_tailed_feature_frequencies_hot_rows(kind, prec, monkeypatch):
     """Real dictionaries are heavy-tailed: here a few features of every layer fire in about half of the tokens (encoder-bias
