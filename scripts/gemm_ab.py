@@ -22,7 +22,7 @@ def load(v):
     lib.clt_gemm_bf16.restype = I
     lib.clt_gemm_bf16.argtypes = [P, P, P, I, I, I, L, L, L, I, I, I, L, L, L, P, L, I, P]
     lib.clt_gemm_bf16_select.restype = I
-    lib.clt_gemm_bf16_select.argtypes = [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, P]
+    lib.clt_gemm_bf16_select.argtypes = [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, I, P]
     return lib
 
 
@@ -56,7 +56,7 @@ def select_ab(variants, libs, rounds):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = libs[v].clt_gemm_bf16_select(xs.data_ptr(), Wt.data_ptr(), Bn, F, d, Lr * d, d, Lr * F, Lr, d, d * F, F, bias.data_ptr(), F,
-                                              ctl.data_ptr(), ck.data_ptr(), ci.data_ptr(), capS, 0, st)
+                                              ctl.data_ptr(), ck.data_ptr(), ci.data_ptr(), capS, 0, 0, st)
             assert rc == 0, rc
             e1.record()
             torch.cuda.synchronize()
@@ -81,6 +81,9 @@ def shapes():
         ("enc fwd  M4096 K768 N32768 x12", B_, F, d, Lr, Lr * d, d, Lr * F, d, d * F, F),
         ("wgrad    M32768 N768 K4096 x12", F, d, B_, Lr, B_, B_, d, F * B_, d * B_, F * d),
         ("dec fwd  M4096 N768 K32768 x12", B_, d, F, Lr, Lr * F, F, Lr * d, F, d * F, d),
+        ("dec fwd  M4096 N768 K32768 x36", B_, d, F, 36, 36 * F, F, 36 * d, F, d * F, d),
+        ("enc wgr  M32768 N768 K4096 x1 ", F, d, B_, 1, B_, B_, d, 0, 0, 0),
+        ("dgrad    M4096 N32768 K768 x12", B_, F, d, Lr, Lr * d, d, Lr * F, d, d * F, F),
     ]
 
 
