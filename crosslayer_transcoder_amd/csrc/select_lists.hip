@@ -517,7 +517,9 @@ int run_stages(const SelArgs& a, int lo, int hi) {
     // reference's autocast values): with the initial zero bias tens of thousands of entries tie at the k-th value of the
     // headline shape (63 034 measured), far beyond a tie block, and the exhaustive dense fallback would run instead.
     const bool local_radix = !tie_radix && a.sd.world == 1 && mode != 0;
-    const int last_stage = tie_radix ? 8 : (split ? 6 : 5);
+    // (split: stage 6 ends with the token-major lists — all the decoder's gather forward reads — and stage 7 builds the feature-major
+    // ones, so that the caller may queue stage 7 on a second stream beside the forward)
+    const int last_stage = tie_radix ? 8 : (split ? 7 : 5);
     TieX* tiex = (TieX*)(w8 + p.off_tiex);                 // (zeroed in stage 0)
 
     for (int stage = lo; stage <= hi; ++stage) {
@@ -634,7 +636,8 @@ int run_stages(const SelArgs& a, int lo, int hi) {
                                            a.csc_tok, a.csc_val, a.csc_ent, a.fired, a.total, a.overflow, fbbuild, bb, st, gate);
             if (rc != CLT_OK) return rc;
         }
-        if (mode != 0 && a.used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, a.used_fallback);
+        // (split: the outcome was published in stage 5, and this stage may run on another stream than the flag's reader)
+        if (mode != 0 && a.used_fallback && !split) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, a.used_fallback);
     }
     CLT_LAUNCH_CHECK(); return CLT_OK;
 }
@@ -842,7 +845,7 @@ int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, in
                              uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                              float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                              int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
-    if (stage_lo < 0 || stage_hi > 6 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1 || !prev_T) return CLT_ERR_SHAPE;
+    if (stage_lo < 0 || stage_hi > 7 || stage_lo > stage_hi || rank < 0 || rank >= world || mode < 1 || !prev_T) return CLT_ERR_SHAPE;
     if (f_off < 0 || f_off + F > F_global || !(margin > 0.0f && margin <= 1.0f)) return CLT_ERR_SHAPE;
     SelArgs a{nullptr, nullptr, B, L, F, k, mode, threshold, ema_e, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val,
               csc_ent, fired, total, overflow, nullptr, used_fallback, ws, wsb, as_stream(stp),

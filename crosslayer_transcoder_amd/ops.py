@@ -1090,13 +1090,18 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     S = L if mode == SELECT_LAYER else 1
     s = _empty_lists(Bn, L, F, cap, xs.device)
     dims = (Bn, L, F, k, mode, world, 2)
-    ws = workspace(lib.clt_select_lists_sharded_workspace_bytes(*dims), xs.device)
+    # (a workspace of this entry point's own, not the scratch buffer every op of the launch stream shares: stage 7 runs on a
+    # second stream while the launch stream goes on to kernels that take their scratch from ops.workspace)
+    ws = _select_workspace(lib.clt_select_lists_sharded_workspace_bytes(*dims), xs.device)
     off = [lib.clt_select_lists_exchange_info(*dims, w) for w in range(10)]
     i32 = lambda o, n: ws[o:o + 4 * n].view(torch.int32)  # noqa: E731
     exchange = {"lb": i32(off[0], 4 * S).view(S, 4), "hist": i32(off[1], off[2]),
                 "ties": i32(off[3], off[4] * world).view(world, off[4])}
     fb = torch.zeros(1, dtype=torch.int32, device=xs.device)
     base = ws.data_ptr()
+    last = _csc_last.get(xs.device.index or 0)
+    if last is not None:                      # (a step that never asked confirm(): its stage 7 still owns the workspace)
+        torch.cuda.current_stream(xs.device).wait_event(last)
 
     def stages(lo, hi):
         call("clt_select_lists_ext_f32", lo, hi, world, rank, f_off, Fg, prev_T.data_ptr(), float(margin),
@@ -1120,7 +1125,24 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     if speculate is not None or defer:
         s.row_start.zero_()                  # (a void attempt emits nothing: speculative readers then see no entries)
         s.col_start.zero_()
-    stages(6, 6)
+    stages(6, 6)                              # ... token-major lists: what the gather forward reads
+    # stage 7, the feature-major lists (scan, fill, column sorts: short latency-bound launches, half a millisecond on heavy-tailed
+    # lists), on a second stream beside the speculated forward; confirm() — called before anything reads col_start / csc_* /
+    # fired — makes the launch stream wait for it
+    csc_done = None
+    if speculate is not None and LIST_CSC_STREAM and TIMING is None:
+        main, cs = torch.cuda.current_stream(xs.device), _csc_stream(xs.device)
+        _csc_last[xs.device.index or 0] = None
+        ev7 = torch.cuda.Event()
+        ev7.record(main)
+        cs.wait_event(ev7)
+        with torch.cuda.stream(cs):
+            stages(7, 7)
+            csc_done = torch.cuda.Event()
+            csc_done.record(cs)
+        _csc_last[xs.device.index or 0] = csc_done
+    else:
+        stages(7, 7)
     spec = speculate(s) if speculate is not None else None
     side, host = _flag_reader(xs.device)
     with torch.cuda.stream(side):
@@ -1132,6 +1154,8 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     s.speculated = spec
 
     def confirm() -> bool:
+        if csc_done is not None:
+            torch.cuda.current_stream(xs.device).wait_event(csc_done)
         side.synchronize()
         return int(host) == 0
 
@@ -1141,6 +1165,35 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     if not confirm():
         return None, None
     return s, T
+
+
+#: fused encoder + BatchTopK step: the feature-major half of the list build on a stream of its own beside the gather forward
+#: (CLT_AB=list_csc_stream=0: on the launch stream, in front of it)
+LIST_CSC_STREAM = bool(ab_switch("list_csc_stream", 1))
+_csc_streams = {}
+_csc_last = {}             # device -> event of the last stage 7 queued on the second stream
+
+
+_select_ws = {}
+
+
+def _select_workspace(nbytes: int, device) -> torch.Tensor:
+    key = device.index or 0
+    buf = _select_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        last = _csc_last.get(key)
+        if last is not None:                  # (the buffer about to be dropped may still be read by a queued stage 7)
+            torch.cuda.current_stream(device).wait_event(last)
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _select_ws[key] = buf
+    return buf
+
+
+def _csc_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _csc_streams:
+        _csc_streams[key] = torch.cuda.Stream(device=dev)
+    return _csc_streams[key]
 
 
 #: fused encoder + per-row TopK: every ROWS_SAMPLE_STRIDE-th feature is sampled; a row's bound is the j-th largest sampled

@@ -380,7 +380,9 @@ int clt_gemm_bf16_select(const uint16_t* A, const uint16_t* B, int M, int N, int
  * step's exact k-th value, prev_T[S] as order-preserving keys: word 0 of the SegState records, exchange info 6).
  * Stage 0 prepares the workspace (then run the GEMM), stages 1..4 as clt_select_lists_sharded_f32 (workspace /
  * exchange queries with flags = 2); stage 5 merges the outcome over shards and PUBLISHES used_fallback[0], stage 6 emits
- * the selection and builds the lists — so the host can fetch the flag (side stream) while stage 6 runs.
+ * the selection and builds the token-major lists (row_start / ent_col / ent_val: all the decoder's gather forward reads),
+ * stage 7 the feature-major ones (col_start / csc_* / fired) — so the host can fetch the flag (side stream) while stage 6
+ * runs, and may queue stage 7 on a second stream beside the forward (it reads what stage 6 wrote and the workspace).
  * used_fallback[0] != 0: the attempt is void (bound too high, overflow, too many ties, previous value not positive):
  * nothing is emitted, the caller runs the ordinary path.
  * drift (optional, [2 S] floats the caller keeps from step to step, initially zeros: stage 0 tracks the relative
