@@ -129,6 +129,34 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+#: (CLT_AB=table_cache=0: every table uploaded from pageable memory when it is needed, for A/B runs)
+TABLE_CACHE = bool(ab_switch("table_cache", 1))
+_TABLES = {}          # (device index, values) -> (device int64 tensor, pinned source); insertion-ordered, bounded
+_TABLES_MAX = 64
+
+
+def _device_table(values, device) -> torch.Tensor:
+    """Device int64 array of `values` (pointer / offset tables of the grouped and K-segmented GEMMs, of the gather forward).
+    The tables of a training step repeat from step to step (weights, operand copies and — through the caching allocator —
+    even the per-step buffers keep their addresses), and an upload from pageable memory makes the host wait for everything
+    queued before it: 0.4 ms of idle GPU per dense CLT step in front of the feature-gradient GEMMs.  A table is a pure function
+    of its values, so a cached one is valid whenever the same values are asked for again; a new one goes up from pinned
+    memory without blocking."""
+    device = torch.device(device)
+    if not TABLE_CACHE:
+        return torch.tensor(values, dtype=torch.int64).to(device)
+    key = (device.index or 0, tuple(values))
+    hit = _TABLES.get(key)
+    if hit is None:
+        src = torch.tensor(values, dtype=torch.int64).pin_memory()
+        hit = (src.to(device, non_blocking=True), src)
+        if len(_TABLES) >= _TABLES_MAX:       # (rare: a table may still be read by a queued kernel of any stream)
+            torch.cuda.synchronize(device)
+            _TABLES.pop(next(iter(_TABLES)))
+        _TABLES[key] = hit
+    return hit[0]
+
+
 def _rows_view(x: torch.Tensor) -> Tuple[int, int, int]:
     """x: [B, ...] with contiguous inner dims (e.g. batch[:, 0]) -> (rows, n, row_stride)."""
     B = x.shape[0]
@@ -297,7 +325,7 @@ def clt_decoder_dgrad_kseg(g: torch.Tensor, Ws: List[torch.Tensor], out_bf16: bo
     ptrs = []
     for lp in range(L):
         ptrs += [_chk(Ws[l], op16()).data_ptr() + 2 * lp * F * d for l in range(lp, L)]
-    table = torch.tensor(ptrs, dtype=torch.int64).to(g.device)
+    table = _device_table(ptrs, g.device)
     df = torch.empty(Bn, L, F, dtype=op16() if out_bf16 else torch.float32, device=g.device)
     # One persistent block per CU walks 256 x 256 tiles: a launch with a few tiles more than a multiple of 256 (the compacted
     # TopK-aux pass: 16 x 18 = 288) spends a whole extra round on them.  The L launches write disjoint columns, so they
@@ -422,7 +450,7 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
                 for lp in range(l + 1):
                     rec += [lp * F, wt + 2 * lp * d * F, slabs.data_ptr() + p * slab_b]
                     p += 1
-            table = torch.tensor(rec, dtype=torch.int64).to(fo.device)
+            table = _device_table(rec, fo.device)
             rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, op16()).data_ptr(),
                             table.data_ptr(), P, Bn, d, F, L * F, F, d, _stream())
             if rc == 1 and l0 == 0:
@@ -470,7 +498,7 @@ def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Ten
         _chk(outs[l])
         for lp in range(l + 1):
             rec += [lp * F * Bn, gT.data_ptr() + 2 * l * d * Bn, outs[l].data_ptr() + 4 * lp * F * d]
-    table = torch.tensor(rec, dtype=torch.int64).to(fT.device)
+    table = _device_table(rec, fT.device)
     P = L * (L + 1) // 2
     rc = _timed_raw("gemm", 2.0 * F * d * Bn * P, "clt_gemm_bf16_nt_grouped", fT.data_ptr(), table.data_ptr(), P, F, d, Bn, Bn, Bn, d,
                     _stream())
@@ -1383,7 +1411,7 @@ def select_rows_sharded(x: torch.Tensor, k: int, shard, col_mask: Optional[torch
 
 def pointer_table(tensors: List[torch.Tensor]) -> torch.Tensor:
     """Device array of device pointers (one small H2D copy; cache it while the storages are stable)."""
-    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(tensors[0].device)
+    return _device_table([t.data_ptr() for t in tensors], tensors[0].device)
 
 
 def sparse_decoder_fwd(s: SparseLists, wptr: torch.Tensor, bias: Optional[torch.Tensor], d: int, cross_layer: bool,
