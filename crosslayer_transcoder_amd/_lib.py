@@ -109,7 +109,7 @@ SIGNATURES = {
     "clt_adam_prep_f32": (I, [P, P, P, P, I, I, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, P, P, P]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class CltError(RuntimeError):

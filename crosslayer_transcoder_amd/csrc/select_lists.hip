@@ -722,13 +722,14 @@ size_t clt_select_rows_ext_info(int B, int L, int F, int k, int slots, int Fs, i
     switch (which) { case 0: return p.off_lb; case 1: return p.off_slotcnt; case 2: return p.off_skey; case 3: return p.off_sslot; default: return 0; }
 }
 // stage 0: clear the counters, row bounds from the sampled pre-activations pre_s [B*L][Fs]  (then run clt_gemm_bf16_select_rows);
-// stage 1: check every row's slot block and PUBLISH used_fallback[0] (1: void attempt); stage 2: exact selection per row + lists
-// (nothing is emitted after a void attempt: all rows empty).  The host may read the flag while stage 2 runs.
+// stage 1: check every row's slot block and PUBLISH used_fallback[0] (1: void attempt); stage 2: exact selection per row + the
+// token-major lists, stage 3: the feature-major lists (nothing is emitted after a void attempt: all rows empty).  The host may
+// read the flag while stage 2 runs, and stage 3 may be queued on a second stream beside the decoder's gather forward.
 int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int B, int L, int F, int k, int slots, int Fs, int j,
                             uint32_t cap, uint32_t* row_start, int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok,
                             float* csc_val, int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow,
                             int32_t* used_fallback, void* ws, size_t wsb, void* stp) {
-    if (!rows_ext_ok(B, L, F, k, slots, Fs, j) || stage_lo < 0 || stage_hi > 2 || stage_lo > stage_hi || cap == 0) return CLT_ERR_SHAPE;
+    if (!rows_ext_ok(B, L, F, k, slots, Fs, j) || stage_lo < 0 || stage_hi > 3 || stage_lo > stage_hi || cap == 0) return CLT_ERR_SHAPE;
     const RPlan p = rplan(B, L, F, k, slots, Fs, j);
     if (!ws || wsb < p.total) return CLT_ERR_WORKSPACE;
     hipStream_t st = as_stream(stp);
@@ -761,13 +762,14 @@ int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int 
         } else if (stage == 1) {
             hipLaunchKernelGGL(rows_check_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, slot_cnt, lb, rows, k, slots, head);
             if (used_fallback) hipLaunchKernelGGL(publish_gate_kernel, dim3(1), dim3(1), 0, st, head, used_fallback);
-        } else {
+        } else if (stage == 2) {
             const int rc = clt_internal_topk_merge_slots((const uint32_t*)(w8 + p.off_skey), (const int32_t*)(w8 + p.off_sslot), slot_cnt, slots, k,
                                                          F, L, rows, sidx, sval, row_cnt, col_cnt, gate, st);
             if (rc != CLT_OK) return rc;
             launch_scan(row_cnt, rows, row_start, total, (uint8_t*)nullptr, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);   // (long_list is idle until the row sort)
             hipLaunchKernelGGL(compact_rows_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, sidx, sval, k, F, L, rows, row_start, cap, ent_col,
                                ent_val, overflow);
+        } else {                                           // stage 3: the feature-major lists from the finished token-major ones
             launch_scan(col_cnt, ncols, col_start, nullptr, fired, (const int32_t*)nullptr, 0, (uint32_t*)long_list, st);
             hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap, col_start,
                                col_cur, csc_tok, csc_val, csc_ent, (const int32_t*)nullptr, 0);

@@ -1127,9 +1127,7 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
                 "ties": i32(off[3], off[4] * world).view(world, off[4])}
     fb = torch.zeros(1, dtype=torch.int32, device=xs.device)
     base = ws.data_ptr()
-    last = _csc_last.get(xs.device.index or 0)
-    if last is not None:                      # (a step that never asked confirm(): its stage 7 still owns the workspace)
-        torch.cuda.current_stream(xs.device).wait_event(last)
+    _wait_last_csc(xs.device)
 
     def stages(lo, hi):
         call("clt_select_lists_ext_f32", lo, hi, world, rank, f_off, Fg, prev_T.data_ptr(), float(margin),
@@ -1157,20 +1155,7 @@ def encoder_select_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[torch.T
     # stage 7, the feature-major lists (scan, fill, column sorts: short latency-bound launches, half a millisecond on heavy-tailed
     # lists), on a second stream beside the speculated forward; confirm() — called before anything reads col_start / csc_* /
     # fired — makes the launch stream wait for it
-    csc_done = None
-    if speculate is not None and LIST_CSC_STREAM and TIMING is None:
-        main, cs = torch.cuda.current_stream(xs.device), _csc_stream(xs.device)
-        _csc_last[xs.device.index or 0] = None
-        ev7 = torch.cuda.Event()
-        ev7.record(main)
-        cs.wait_event(ev7)
-        with torch.cuda.stream(cs):
-            stages(7, 7)
-            csc_done = torch.cuda.Event()
-            csc_done.record(cs)
-        _csc_last[xs.device.index or 0] = csc_done
-    else:
-        stages(7, 7)
+    csc_done = _fork_csc(xs.device, lambda: stages(7, 7), speculate is not None)
     spec = speculate(s) if speculate is not None else None
     side, host = _flag_reader(xs.device)
     with torch.cuda.stream(side):
@@ -1215,6 +1200,32 @@ def _select_workspace(nbytes: int, device) -> torch.Tensor:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _select_ws[key] = buf
     return buf
+
+
+def _fork_csc(device, run_stage, enabled: bool):
+    """Queue `run_stage()` — the feature-major half of a list build — on the second stream behind what the launch stream holds
+    so far; returns the event that marks its end (None: it ran on the launch stream)."""
+    if not (enabled and LIST_CSC_STREAM and TIMING is None):
+        run_stage()
+        return None
+    key = device.index or 0
+    main, cs = torch.cuda.current_stream(device), _csc_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    cs.wait_event(ev)
+    with torch.cuda.stream(cs):
+        run_stage()
+        done = torch.cuda.Event()
+        done.record(cs)
+    _csc_last[key] = done
+    return done
+
+
+def _wait_last_csc(device):
+    """(a step that never asked confirm(): its feature-major stage still owns the selection workspace)"""
+    last = _csc_last.get(device.index or 0)
+    if last is not None:
+        torch.cuda.current_stream(device).wait_event(last)
 
 
 def _csc_stream(dev):
@@ -1291,9 +1302,10 @@ def encoder_select_rows_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[to
     offset = int(offset) % stride
     dev = xs.device
     dims = (Bn, L, F, k, slots, Fs, j)
-    ws = workspace(lib.clt_select_rows_ext_workspace_bytes(*dims), dev)
+    ws = _select_workspace(lib.clt_select_rows_ext_workspace_bytes(*dims), dev)     # (its own: stage 3 runs on a second stream)
     off = [lib.clt_select_rows_ext_info(*dims, w) for w in range(4)]
     base = ws.data_ptr()
+    _wait_last_csc(dev)
     s = _empty_lists(Bn, L, F, max(1, k * Bn * L), dev)
     fb = torch.zeros(1, dtype=torch.int32, device=dev)
     pre_s = torch.empty(Bn, L, Fs, dtype=torch.float32, device=dev)
@@ -1315,7 +1327,8 @@ def encoder_select_rows_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[to
     stages(1, 1)                         # outcome flag published: the host read below completes while stage 2 runs
     ev = torch.cuda.Event()
     ev.record()
-    stages(2, 2)
+    stages(2, 2)                         # ... selection + token-major lists; stage 3 (feature-major lists) beside the forward
+    csc_done = _fork_csc(dev, lambda: stages(3, 3), speculate is not None)
     spec = speculate(s) if speculate is not None else None
     side, host = _flag_reader(dev)
     with torch.cuda.stream(side):
@@ -1326,6 +1339,8 @@ def encoder_select_rows_lists(xs: torch.Tensor, Wt: torch.Tensor, b: Optional[to
     s.speculated = spec
 
     def confirm() -> bool:
+        if csc_done is not None:
+            torch.cuda.current_stream(dev).wait_event(csc_done)
         side.synchronize()
         return int(host) == 0
 

@@ -403,7 +403,9 @@ int clt_select_lists_ext_f32(int stage_lo, int stage_hi, int world, int rank, in
  *      block b * L + l (row_lb / slot_cnt / slot_key / slot_idx = workspace + clt_select_rows_ext_info(..., 0 / 1 / 2 / 3));
  *   4. stage 1: used_fallback[0] = 1 when some row's block overflowed or holds fewer than k candidates under a positive bound
  *      (the sample's j-th largest was above the row's k-th value: probability C(k-1, j) / stride^j per row) — the attempt is
- *      void, stage 2 then emits empty lists and the caller reruns the unfused GEMM + selection; stage 2: selection + lists. */
+ *      void, stage 2 then emits empty lists and the caller reruns the unfused GEMM + selection; stage 2: selection + the
+ *      token-major lists (what the decoder's gather forward reads); stage 3: the feature-major lists (col_start / csc_* / fired),
+ *      which may be queued on a second stream beside the forward (it reads what stage 2 wrote and the workspace). */
 size_t clt_select_rows_ext_workspace_bytes(int B, int L, int F, int k, int slots, int Fs, int j);
 size_t clt_select_rows_ext_info(int B, int L, int F, int k, int slots, int Fs, int j, int which);
 int clt_select_rows_ext_f32(int stage_lo, int stage_hi, const float* pre_s, int B, int L, int F, int k, int slots, int Fs, int j,
