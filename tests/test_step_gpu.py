@@ -646,36 +646,45 @@ def test_debug_yaml_config_end_to_end(tmp_path, golden):
 
 
 @pytest.mark.parametrize("prec", ["32", "bf16-mixed"])
-def test_hot_rows_on_their_own_stream_give_the_same_bits(prec, monkeypatch):
-    """engine.HOT_ROWS_STREAM: the hot rows' launches of every weight pass queued on a second stream (hot_phase 1 / 2 of
-    clt_sparse_row_pass_f32) touch rows and dot slots of their own — three fused Adam steps leave every parameter and moment
-    bit-identical to the one-stream order."""
+@pytest.mark.parametrize("kind", ["batchtopk", "topk"])
+def test_second_streams_give_the_same_bits(kind, prec, monkeypatch):
+    """The step's second streams — engine.HOT_ROWS_STREAM (the hot rows' launches of every weight pass, hot_phase 1 / 2 of
+    clt_sparse_row_pass_f32) and ops.LIST_CSC_STREAM (the feature-major half of the fused selections' list build, stage 7 / 3 of
+    the ext entry points) — only reorder independent work: eight fused Adam steps over two batches leave every parameter and
+    moment bit-identical to the one-stream order, with heavy-tailed lists (hot columns present) and the fused selections active."""
     from crosslayer_transcoder_amd import engine, ops, precision
     from tests.build_cases import build_module
     B, L, d, F, k = 768, 3, 128, 512, 8
     g = torch.Generator().manual_seed(29)
-    x = torch.randn(B, L, d, generator=g)
-    y = 0.5 * x * torch.randn(L, d, generator=g) + 0.1 * torch.randn(B, L, d, generator=g)
-    batch = torch.stack([x, y], 1)
+    batches = []
+    A = torch.randn(L, d, generator=g)
+    for _ in range(2):
+        x = torch.randn(B, L, d, generator=g)
+        batches.append(torch.stack([x, 0.5 * x * A + 0.1 * torch.randn(B, L, d, generator=g)], 1))
     params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F),
               "decoder.b": torch.randn(L, d, generator=g) * 0.01}
     params["encoder.b"][:, 5::97] = 0.9
     for l in range(L):
         params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
-    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": {"kind": "batchtopk", "k": k, "e": 0.1}, "loss": {"kind": "base"}},
-            "opt": {"lr": 1e-3}, "batches": batch[None], "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long),
+    nl = {"kind": "batchtopk", "k": k, "e": 0.1} if kind == "batchtopk" else {"kind": "topk", "k": k}
+    case = {"cfg": {"decoder": "clt", "d_features": F, "nonlinearity": nl, "loss": {"kind": "base"}},
+            "opt": {"lr": 1e-3}, "batches": torch.stack(batches), "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long),
             "max_steps": 10}
     res = {}
     for on in (True, False):
         monkeypatch.setattr(engine, "HOT_ROWS_STREAM", on)
+        monkeypatch.setattr(ops, "LIST_CSC_STREAM", on)
+        fused0 = engine.STATS["fused_select_steps"]
         mod = build_module(case)
         mod.log_metrics_every = 0
         opt, _ = mod.attach_optimizers()
         with precision(prec):
-            for t in range(3):
-                mod.fused_train_step(batch.cuda(), t, opt)
+            for t in range(8):
+                mod.fused_train_step(batches[t % 2].cuda(), t, opt)
         S = mod.last_step["lists"]
         assert ops.hot_columns(S) is not None and int((S.col_start[1:] - S.col_start[:-1]).max()) > 256
+        if prec != "32" and kind == "batchtopk":      # (the fused encoder + selection runs in the 16-bit modes, from the second step on)
+            assert engine.STATS["fused_select_steps"] - fused0 == 7
         torch.cuda.synchronize()
         res[on] = {k_: (p.detach().clone(), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
                    for k_, p in mod.model.named_parameters()}
