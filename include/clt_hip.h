@@ -355,11 +355,12 @@ int clt_gemm_bf16_nt_kseg_out16(const uint16_t* A, const uint16_t* const* Bseg, 
  * piece land; 0 (default): by shape, form 2 for 2048 <= K <= 8192 (profiles/r03_gemm_ab.md).  `reserved` is ignored.  Results
  * are bit-identical between the forms (same k order per element).  Returns the previous form. */
 int clt_gemm_nt_variant(int variant, int reserved);
-/* Co-scheduling hook (no counterpart in the reference): > 0 = the persistent grid of every NT-kernel launch made while it is set
- * takes at most `blocks` workgroups (rounded down to a multiple of 8; one workgroup fills a CU), leaving the other CUs to a
- * bandwidth-bound kernel that runs beside it on another stream — the next step's encoder GEMM under the optimizer's weight passes
- * (engine.OVERLAP_ENCODER).  0 = one workgroup per CU (default); negative = query only.  Results do not depend on it (same k
- * order per element).  Process-wide host state: set it around the launch.  Returns the previous value. */
+/* Test / probe hook (no counterpart in the reference; no product path sets it): > 0 = the persistent grid of every NT-kernel
+ * launch made while it is set takes at most `blocks` workgroups (rounded down to a multiple of 8; one workgroup fills a CU),
+ * leaving the other CUs to a kernel that runs beside it on another stream.  Used by scripts/archive/overlap_probe.py, which
+ * measured what co-scheduling the next step's encoder GEMM with the optimizer's weight passes would gain (0.26 of 12.68 ms at
+ * best: profiles/r03_overlap_probe.txt).  0 = one workgroup per CU (default); negative = query only.  Results do not depend on
+ * it (same k order per element).  Process-wide host state.  Returns the previous value. */
 int clt_gemm_nt_grid_limit(int blocks);
 /* Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
  * groups: DEVICE array of records {int64 aoff (elements into A); const uint16_t* B; float* C}.  Used for the dense
