@@ -133,6 +133,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 TABLE_CACHE = bool(ab_switch("table_cache", 1))
 _TABLES = {}          # (device index, values) -> (device int64 tensor, pinned source); insertion-ordered, bounded
 _TABLES_MAX = 64
+_TABLES_OLD = []
 
 
 def _device_table(values, device) -> torch.Tensor:
@@ -150,9 +151,12 @@ def _device_table(values, device) -> torch.Tensor:
     if hit is None:
         src = torch.tensor(values, dtype=torch.int64).pin_memory()
         hit = (src.to(device, non_blocking=True), src)
-        if len(_TABLES) >= _TABLES_MAX:       # (rare: a table may still be read by a queued kernel of any stream)
-            torch.cuda.synchronize(device)
-            _TABLES.pop(next(iter(_TABLES)))
+        if len(_TABLES) >= _TABLES_MAX:
+            # (an evicted table may still be read by a queued kernel of any stream: it stays alive for another _TABLES_MAX
+            # evictions — whole steps later — instead of being freed, or waited for, now)
+            _TABLES_OLD.append(_TABLES.pop(next(iter(_TABLES))))
+            if len(_TABLES_OLD) > _TABLES_MAX:
+                _TABLES_OLD.pop(0)
         _TABLES[key] = hit
     return hit[0]
 
