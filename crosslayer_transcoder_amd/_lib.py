@@ -67,8 +67,8 @@ SIGNATURES = {
     "clt_dead_update": (I, [P, I, L, P, L, P, P, P]),
     "clt_sparse_build_workspace_bytes": (SZ, [I, I, I]),
     "clt_sparse_build_f32": (I, [P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
-    "clt_sparse_build_threshold_f32": (I, [P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
-    "clt_sparse_build_threshold_x16": (I, [P, P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "clt_sparse_build_threshold_f32": (I, [P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, I, P]),
+    "clt_sparse_build_threshold_x16": (I, [P, P, P, I, I, I, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, SZ, I, P]),
     "clt_select_lists_workspace_bytes": (SZ, [I, I, I, I, I]),
     "clt_select_lists_f32": (I, [P, P, I, I, I, I, I, P, F32, C.c_uint32, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     "clt_select_lists_sharded_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
@@ -109,7 +109,7 @@ SIGNATURES = {
     "clt_adam_prep_f32": (I, [P, P, P, P, I, I, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, P, P, P]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class CltError(RuntimeError):

@@ -125,7 +125,7 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
                               const int32_t* gate, const float* theta = nullptr, bool theta_gate = false, bool x16 = false,
-                              const float* bias = nullptr);
+                              const float* bias = nullptr, int phase = 0);
 int clt_internal_topk_segmented(const float* x, float* feat, int B, int L, int F, int k, int per_layer, float* threshold,
                                 float e, void* ws, size_t wsb, hipStream_t st, const int32_t* gate);
 int clt_internal_topk_rows(const float* x, float* feat, int rows, int F, int k, int32_t* idx_out, float* val_out,

@@ -864,7 +864,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_sparse)
 int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t cap, uint32_t* row_start, int32_t* ent_col,
                               float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val, int32_t* csc_ent,
                               uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb, hipStream_t st,
-                              const int32_t* gate, const float* theta, bool theta_gate, bool x16, const float* bias) {
+                              const int32_t* gate, const float* theta, bool theta_gate, bool x16, const float* bias, int phase) {
     const int xt = x16 ? (clt_host_state.fp16 ? 2 : 1) : 0;     // element type of feat: fp32 / bf16 / fp16
     if (B <= 0 || L <= 0 || F <= 0 || cap == 0) return CLT_ERR_SHAPE;
     if ((unsigned long long)L * F >= 0x7fffffffull || (unsigned long long)B * L >= 0x7fffffffull) return CLT_ERR_RANGE;
@@ -877,16 +877,22 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
     int32_t* long_list = (int32_t*)(cursor + ncols);
     uint32_t* long_count = (uint32_t*)(long_list + ncols);
     uint32_t* wave_cnt = long_count + 64;                  // [rows][4]: per-wave entry counts, count_rows -> fill_rows
+    // phase (threshold lists): 0 = the whole build; 1 = counts, row offsets and the gate (overflow is final); 2 = the token-major
+    // lists; 3 = the feature-major lists from them (the caller may queue phase 3 on a second stream: it reads what the earlier
+    // phases wrote and the workspace)
+    const dim3 g4((unsigned)(((B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * L));
+    const bool th4 = F % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & (uintptr_t)(xt == 0 ? 15 : 7)) == 0 &&
+                     (!theta || (reinterpret_cast<uintptr_t>(theta) & 15) == 0);
+    if (bias && (!th4 || (reinterpret_cast<uintptr_t>(bias) & 15))) return CLT_ERR_ALIGN;      // (a bias only in the vector form)
+    if (phase >= 2) {
+        if (own_gate) gate = (int32_t*)(long_count + 8);
+    } else {
     if (!gate) {            // the gated caller clears these itself (a memset cannot be gated)
         if (hipMemsetAsync(col_cnt, 0, (size_t)2 * ncols * sizeof(uint32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(long_count, 0, 64, st) != hipSuccess) return CLT_ERR_LAUNCH;
         if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return CLT_ERR_LAUNCH;
     }
     // thresholds + vector form (every row has it when the bases are aligned and F % 4 == 0): four rows of a layer per block
-    const bool th4 = F % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & (uintptr_t)(xt == 0 ? 15 : 7)) == 0 &&
-                     (!theta || (reinterpret_cast<uintptr_t>(theta) & 15) == 0);
-    if (bias && (!th4 || (reinterpret_cast<uintptr_t>(bias) & 15))) return CLT_ERR_ALIGN;      // (a bias only in the vector form)
-    const dim3 g4((unsigned)(((B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * L));
     if (th4) {
 #define COUNT_ROWS_TH(XT_)                                                                                                 \
     do {                                                                                                                    \
@@ -905,6 +911,9 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
         hipLaunchKernelGGL(list_gate_kernel, dim3(1), dim3(1), 0, st, total, cap, gw, overflow);
         gate = gw;
     }
+    if (phase == 1) { CLT_LAUNCH_CHECK(); return CLT_OK; }
+    }
+    if (phase <= 2) {
 #define FILL_ROWS(XT_) hipLaunchKernelGGL((fill_rows_kernel<XT_>), dim3(rows), dim3(TPB), 0, st, feat, F, L, theta, row_start, ent_col, ent_val, cap, \
                                           overflow, gate, 1, (const uint32_t*)wave_cnt)
 #define FILL_ROWS_TH(XT_)                                                                                                  \
@@ -918,6 +927,8 @@ int clt_internal_sparse_build(const void* feat, int B, int L, int F, uint32_t ca
     else if (xt == 0) FILL_ROWS(0); else if (xt == 1) FILL_ROWS(1); else FILL_ROWS(2);
 #undef FILL_ROWS
 #undef FILL_ROWS_TH
+    if (phase == 2) { CLT_LAUNCH_CHECK(); return CLT_OK; }
+    }
     hipLaunchKernelGGL(count_cols_kernel, dim3(1024), dim3(TPB), 0, st, ent_col, total, cap, col_cnt, gate, 1);
     launch_scan(col_cnt, ncols, col_start, nullptr, fired, gate, 1, (uint32_t*)long_list, st);   // (long_list is idle until sort_cols)
     hipLaunchKernelGGL(fill_cols_kernel, dim3((rows + 3) / 4), dim3(TPB), 0, st, row_start, ent_col, ent_val, rows, L, cap,
@@ -945,18 +956,20 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
 int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb,
-                                   void* stp) {
+                                   int phase, void* stp) {
+    if (phase < 0 || phase > 3) return CLT_ERR_SHAPE;
     return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
-                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true);
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, false, nullptr, phase);
 }
 
 int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, const float* bias, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* ws, size_t wsb,
-                                   void* stp) {
+                                   int phase, void* stp) {
+    if (phase < 0 || phase > 3) return CLT_ERR_SHAPE;
     if (F % 4 || (reinterpret_cast<uintptr_t>(x) & 7)) return CLT_ERR_ALIGN;
     return clt_internal_sparse_build(x, B, L, F, cap, row_start, ent_col, ent_val, col_start, csc_tok, csc_val, csc_ent, fired,
-                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, true, bias);
+                                     total, overflow, ws, wsb, as_stream(stp), nullptr, theta, true, true, bias, phase);
 }
 
 int clt_sparse_decoder_fwd_f32(const uint32_t* row_start, const int32_t* ent_col, const float* ent_val, const float* const* Wptr,

@@ -534,13 +534,16 @@ def _threshold_lists(mod, pre, theta, force: bool, bias=None):
     when more than LIST_MAX_DENSITY of the entries are active (the dense regime is then cheaper).  force: no gate."""
     Bn, L, F = pre.shape
     full = Bn * L * F
+    # (split build: the host reads the gate's outcome while the lists are still being filled, and the feature-major half runs on
+    # the list builds' second stream beside the gather forward; the step joins it before it reads col_start / csc_* / fired)
     if force:
-        return ops.sparse_build_threshold(pre, theta, full, bias)
+        return ops.sparse_build_threshold(pre, theta, full, bias, split=True)
     if getattr(mod, "_list_skip", 0) > 0:            # recently above the break-even: no attempt this step
         mod._list_skip -= 1
         return None
-    S = ops.sparse_build_threshold(pre, theta, max(1, int(LIST_MAX_DENSITY * full)), bias)
-    if ops.read_flag(S.overflow) != 0:
+    S = ops.sparse_build_threshold(pre, theta, max(1, int(LIST_MAX_DENSITY * full)), bias, split=True)
+    if S.overflowed():
+        S.join()                                     # (its gated-off kernels still hold the lists' memory)
         mod._list_retry = min(LIST_RETRY_MAX, 2 * getattr(mod, "_list_retry", LIST_RETRY_FIRST // 2))
         mod._list_skip = mod._list_retry
         STATS["list_gate_dense"] = STATS.get("list_gate_dense", 0) + 1
@@ -1153,6 +1156,9 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
         fired = ops.column_any_positive(feat)
 
     def dead_features():
+        join = getattr(S, "join", None) if S is not None else None
+        if join is not None:                  # (threshold lists: `fired` comes with the feature-major half of the build)
+            join()
         dd, cnt = ops.dead_update(fired, Bn, mod.last_active, mod.tokens_till_dead)
         if shard is not None:                 # features are split over ranks: count over all shards
             if pipelined:

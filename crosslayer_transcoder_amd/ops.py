@@ -907,7 +907,7 @@ def adam_prep(p, g, m, v, step: int, lr: float, beta1, beta2, eps, weight_decay,
 class SparseLists:
     """Token-major CSR + feature-major CSC lists of the active features (include/clt_hip.h, sparse section)."""
     __slots__ = ("B", "L", "F", "cap", "row_start", "ent_col", "ent_val", "col_start", "csc_tok", "csc_val",
-                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth", "tie_radix", "speculated", "confirm", "hot")
+                 "csc_ent", "fired", "total", "overflow", "used_fallback", "kth", "tie_radix", "speculated", "confirm", "hot", "overflowed", "join")
 
 
 def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
@@ -935,12 +935,17 @@ def sparse_build(feat: torch.Tensor, cap: int) -> SparseLists:
     return s
 
 
-def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int, bias: Optional[torch.Tensor] = None) -> SparseLists:
+def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: int, bias: Optional[torch.Tensor] = None,
+                           split: bool = False) -> SparseLists:
     """Lists of JumpReLU(x) (theta [1, L, F]) or ReLU(x) (theta None) straight from the pre-activations x [B, L, F]:
     entries = positions with x > theta and x > 0 (x fp32, or 16-bit in the active operand format: values widened; a 16-bit
     x may hold the encoder product alone, the fp32 `bias` [L, F] is then added to the widened values first).  `overflow`
     (device int32 [1]) = 1 when more than `cap` entries exist
-    (the lists are then incomplete and the caller takes the dense regime); `total` holds the true count."""
+    (the lists are then incomplete and the caller takes the dense regime); `total` holds the true count.
+    split: phases 1 (counts, offsets, `overflow`) and 2 (token-major lists) on the launch stream, phase 3 (feature-major lists) on
+    the second stream of the list builds; the result then carries `overflowed()` -> bool — one host read, of a flag that is final
+    BEFORE the lists are filled, so the launch queue does not drain behind it — and `join()`, which makes the launch stream
+    wait for phase 3 and has to be called before anything reads col_start / csc_* / fired."""
     x16 = x.dtype in _DT16
     _chk(x, x.dtype)
     assert x.dtype == torch.float32 or (x.dtype == op16() and x.shape[-1] % 4 == 0)
@@ -953,14 +958,48 @@ def sparse_build_threshold(x: torch.Tensor, theta: Optional[torch.Tensor], cap: 
         _chk(bias)
         assert bias.numel() == L * F
     s = _empty_lists(Bn, L, F, int(cap), x.device)
-    ws = workspace(lib.clt_sparse_build_workspace_bytes(Bn, L, F), x.device)
+    split = bool(split and LIST_CSC_STREAM and TIMING is None)
+    need = lib.clt_sparse_build_workspace_bytes(Bn, L, F)
+    if split:                                   # (phase 2 runs beside kernels that take their scratch from ops.workspace)
+        ws = _select_workspace(need, x.device)
+        _wait_last_csc(x.device)
+    else:
+        ws = workspace(need, x.device)
     extra = ((bias.data_ptr() if bias is not None else None),) if x16 else ()
-    call("clt_sparse_build_threshold_x16" if x16 else "clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, *extra, Bn, L, F, s.cap,
-         s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
-         s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
-         ws.data_ptr(), ws.numel(), _stream())
+
+    def phase(ph):
+        call("clt_sparse_build_threshold_x16" if x16 else "clt_sparse_build_threshold_f32", x.data_ptr(), theta.data_ptr() if theta is not None else None, *extra, Bn, L, F, s.cap,
+             s.row_start.data_ptr(), s.ent_col.data_ptr(), s.ent_val.data_ptr(), s.col_start.data_ptr(), s.csc_tok.data_ptr(),
+             s.csc_val.data_ptr(), s.csc_ent.data_ptr(), s.fired.data_ptr(), s.total.data_ptr(), s.overflow.data_ptr(),
+             ws.data_ptr(), ws.numel(), ph, _stream())
+
     s.used_fallback = None
     s.kth = None
+    flag, dev = s.overflow, x.device            # (the closures below must hold neither the lists — a cycle — nor x)
+    if not split:
+        phase(0)
+        s.overflowed = lambda: read_flag(flag) != 0
+        s.join = lambda: None
+        return s
+    phase(1)                                    # counts, offsets, gate: `overflow` is final
+    ev = torch.cuda.Event()
+    ev.record()
+    side, host = _flag_reader(dev)
+    with torch.cuda.stream(side):               # (the flag's copy waits for phase 1 alone, not for the fill or the forward)
+        side.wait_event(ev)
+        host.copy_(flag, non_blocking=True)
+    phase(2)                                    # token-major lists
+    done = _fork_csc(dev, lambda: phase(3), True)
+
+    def overflowed() -> bool:
+        side.synchronize()
+        return int(host) != 0
+
+    def join():
+        if done is not None:
+            torch.cuda.current_stream(dev).wait_event(done)
+
+    s.overflowed, s.join = overflowed, join
     return s
 
 

@@ -284,11 +284,15 @@ int clt_sparse_build_f32(const float* feat, int B, int L, int F, uint32_t cap, u
 /* The same lists straight from the pre-activations x [B][L][F] of a thresholding sparsifier — JumpReLU (theta [L*F],
  * jumprelu.py:33-37: entries = positions with x > theta and x > 0, value x) or ReLU (theta == NULL: x > 0) — without a
  * dense feature tensor.  When more than `cap` entries exist, overflow[0] = 1 and the lists are incomplete: `cap` is the
- * caller's break-even between the list regime and the dense GEMM regime (total[0] always holds the true count). */
+ * caller's break-even between the list regime and the dense GEMM regime (total[0] always holds the true count).
+ * phase: 0 = the whole build; 1 = counts, row offsets and overflow[0] (final here: the host may fetch it while the lists are
+ * filled); 2 = the token-major lists (row_start / ent_col / ent_val: all the decoder's gather forward reads); 3 = the feature-major
+ * lists (col_start / csc_* / fired) from what phases 1-2 left in the lists and the workspace — a caller may queue phase 3 on a
+ * second stream beside the forward. */
 int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
-                                   size_t ws_bytes, void* stream);
+                                   size_t ws_bytes, int phase, void* stream);
 /* The same from 16-bit pre-activations (the active operand format: what clt_gemm_bf16_nt_out16 leaves — under the reference's
  * autocast the encoder einsum returns a 16-bit tensor too).  bias (optional, [L*F] fp32, 16-byte aligned): the encoder bias,
  * added in fp32 to the widened value before the comparison (autocast's order, clt.py:165); entry values are widened x (+ bias).
@@ -296,7 +300,7 @@ int clt_sparse_build_threshold_f32(const float* x, const float* theta, int B, in
 int clt_sparse_build_threshold_x16(const uint16_t* x, const float* theta, const float* bias, int B, int L, int F, uint32_t cap, uint32_t* row_start,
                                    int32_t* ent_col, float* ent_val, uint32_t* col_start, int32_t* csc_tok, float* csc_val,
                                    int32_t* csc_ent, uint8_t* fired, uint32_t* total, int32_t* overflow, void* workspace,
-                                   size_t ws_bytes, void* stream);
+                                   size_t ws_bytes, int phase, void* stream);
 /* Selection straight to lists (replaces topk.py:58-61, 84-91, 117-128 + the list build above when the dense
  * feature tensor is not needed).  mode 0: k of F per (b,l) row (k <= 2048); 1: global k*B*L; 2: per layer k*B.
  * x: [B][L][F] fp32 pre-activations; col_mask (optional, uint8 [L*F]): positions with mask 0 count as -inf

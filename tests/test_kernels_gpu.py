@@ -467,6 +467,14 @@ def test_threshold_lists_equal_lists_of_the_thresholded_tensor(ops, B, L, F, x16
     _lists_equal(ops.sparse_build_threshold(x, theta, cap), ops.sparse_build(dense, cap), "threshold lists")
     relu = xf * (xf > 0)
     _lists_equal(ops.sparse_build_threshold(x, None, cap), ops.sparse_build(relu, cap), "relu lists")
+    # the build in phases (gate outcome read early, feature-major lists on the second stream): the same lists after join()
+    S = ops.sparse_build_threshold(x, theta, cap, split=True)
+    assert not S.overflowed()
+    S.join()
+    _lists_equal(S, ops.sparse_build(dense, cap), "threshold lists, phased build")
+    S = ops.sparse_build_threshold(x, theta, max(1, int((dense > 0).sum()) // 2), split=True)      # capacity exceeded: gated off
+    assert S.overflowed() and int(S.total) == int((dense > 0).sum())
+    S.join()
 
 
 @pytest.mark.parametrize("B,L,F,k", [(3, 4, 5, 3), (16, 2, 32, 4), (64, 3, 4096, 16), (9, 2, 70000, 33), (300, 12, 1024, 8),
