@@ -85,7 +85,7 @@ SIGNATURES = {
     "clt_gemm_bf16_nt_kseg_out16": (I, [P, P, P, I, I, I, I, L, L, L, P]),
     "clt_gemm_nt_variant": (I, [I, I]),
     "clt_gemm_nt_grid_limit": (I, [I]),
-    "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, P]),
+    "clt_gemm_bf16_nt_grouped": (I, [P, P, I, I, I, I, L, L, L, I, P]),
     "clt_gemm_bf16_select": (I, [P, P, I, I, I, L, L, L, I, L, L, L, P, L, P, P, P, C.c_uint32, I, I, P]),
     "clt_select_rows_ext_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "clt_select_rows_ext_info": (SZ, [I, I, I, I, I, I, I, I]),
@@ -109,7 +109,7 @@ SIGNATURES = {
     "clt_adam_prep_f32": (I, [P, P, P, P, I, I, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P, P, P, P, P]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class CltError(RuntimeError):

@@ -140,7 +140,8 @@ int clt_internal_row_bounds(const float* x, long rows, int F, int j, float* lb, 
 size_t clt_internal_topk_rows_workspace_bytes(long rows, int F, int k);
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false);
+                              hipStream_t st, const uint16_t* const* Bseg = nullptr, int kts = 0, const void* groups = nullptr, bool out16 = false,
+                              int km = 0);
 int clt_internal_set_state_elementwise(const CltState* s);
 int clt_internal_set_state_sparse(const CltState* s);
 int clt_internal_set_state_gemm_nt(const CltState* s);

@@ -1081,7 +1081,7 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_elementwise)
 // =============================================== C ABI ===============================================
 extern "C" {
 const char* clt_arch(void) { return "gfx950"; }
-int clt_abi_version(void) { return 19; }
+int clt_abi_version(void) { return 20; }
 
 int clt_set_loss_scaling(int fp16_operands, float loss_scale, int32_t* found_inf) {
     if (!(loss_scale > 0.0f) || (fp16_operands && !found_inf)) return CLT_ERR_SHAPE;

@@ -156,9 +156,10 @@ extern "C" int clt_gemm_bf16(const uint16_t* A, const uint16_t* B, float* C, int
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CLT_ERR_SHAPE;
     if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return CLT_ERR_SHAPE;
     if ((long)((M + BM - 1) / BM) > 65535 || batch > 65535) return CLT_ERR_RANGE;
-    if (!transA && transB) {                       // k-contiguous operands: the LDS-DMA / 16x16x32 fast path
+    {   // the LDS-DMA / 16x16x32 fast path: k-contiguous operands (A as [M][K], B as [N][K]) staged as they lie, k-major ones
+        // (transA: A as [K][M]; !transB: B as [K][N]) through the transposed LDS reads of gemm_nt_bf16.hip
         const int rc = clt_internal_gemm_nt_bf16(A, B, C, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, bias, sBias, accumulate,
-                                                 as_stream(stream));
+                                                 as_stream(stream), nullptr, 0, nullptr, false, (transA ? 1 : 0) | (transB ? 0 : 2));
         if (rc <= 0) return rc;
     }
     const bool vec = aligned16(A) && aligned16(B) && (lda % 8 == 0) && (ldb % 8 == 0) && (sA % 8 == 0) && (sB % 8 == 0);

@@ -9,7 +9,8 @@
 // buffered (2 x 64 KB); the LDS image is lane-linear 128-byte rows whose 16-byte chunks are XOR-swizzled with
 // bits 1..3 of the row — applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads —
 // which spreads the 16 rows of a fragment over all 16 slots of the 256-byte bank row.  Blocks are remapped so
-// that each XCD (own L2) works on a contiguous range of tiles.
+// that each XCD (own L2) works on a contiguous range of tiles.  Either operand may also be K-MAJOR ([K][rows]: template
+// flags KMA / KMB, see the kernel) — the same kernel then serves all four transpose forms of clt_gemm_bf16.
 #include <type_traits>
 #include <stdlib.h>
 #include "common.h"
@@ -87,7 +88,31 @@ constexpr bool is_select(int epi) { return epi == 1 || epi == 3; }
 // on the K = 768 encoder shapes, whose cost is the store traffic itself (the storers issue twice the stores while the loaders
 // idle at the slab barriers).  The host picks the form by K.  (The loaders' piece offsets: one per-lane offset per operand,
 // the pieces' row stride in the scalar offset; per-piece clamped offsets only on edge tiles — sixteen per-lane offsets spill.)
-template <int EPI, bool F16 = false, bool SPEC = false>
+// KMA / KMB (round 3, fp32 store epilogue, every wave loading): the A / B operand is K-MAJOR — stored [K][rows], the layout a
+// contraction over the outer index of a row-major tensor has (weight gradients: K = tokens; decoder forward: K = features of a
+// [F][d] weight) — so those contractions need no transposed 16-bit copy of their operands.  Its tile is staged as 64 k-rows of
+// 512 B (a DMA piece = two k-rows), 32-byte column pairs XOR-swizzled with km_f(k) (bits 0, 1 and 3 of k: the eight k-rows a
+// 32-lane half of a transposed read touches land in eight different 32-byte bank groups), and the MFMA fragments come out of it
+// with ds_read_b64_tr_b16: per 16-lane group a block of 4 k-rows x 16 columns delivered column-major, two reads per fragment
+// (k + 0..3, k + 4..7) — the same bytes per fragment as the one b128 read of the k-contiguous image.
+// (the compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 — the builtin's memory operand carries no alias scope —
+// while an LDS-DMA load IT knows of is in flight, which would serialise the operand ring; the k-major instantiations therefore
+// issue their DMA pieces through inline asm (m0 = LDS address, as the builtin does) and wait for them with the explicit
+// s_waitcnt vmcnt the kernel uses anyway.  The compiler's own vmcnt accounting stays conservative: operations it does not
+// know of only make its waits longer.)
+__device__ __forceinline__ int km_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 rsrc_words(const void* p, int records) {
+    const unsigned long a = (unsigned long)p;
+    return i32x4{__builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)), __builtin_amdgcn_readfirstlane((int)(a >> 32) & 0xffff), records, 0x00020000};
+}
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned char* lds, int voff, int soff) {
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned at = (unsigned)(unsigned long)(lds_void_t*)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(at), "v"(voff), "s"(rsrc), "s"(soff));
+}
+
+template <int EPI, bool F16 = false, bool SPEC = false, bool KMA = false, bool KMB = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A0, const uint16_t* __restrict__ B0,
                                                            float* __restrict__ C0, int M, int N, int K, long lda, long ldb,
                                                            long ldc, long sA, long sB, long sC, const float* __restrict__ bias0,
@@ -101,6 +126,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
 #endif
     // gflags: CLT_GEMM_ACCUMULATE (C +=), CLT_GEMM_ROUND_ACC (the product is rounded to the operand format before the bias is
     // added: the encoder forward of the 16-bit modes, whose einsum result is a 16-bit tensor under the reference's autocast)
+    static_assert(!(KMA || KMB) || (EPI == 0 && !SPEC), "k-major operands: fp32 store epilogue, every wave loading");
     const int accumulate = EPI == 0 ? (gflags & CLT_GEMM_ACCUMULATE) : 0;
     const bool racc = EPI != 2 && (gflags & CLT_GEMM_ROUND_ACC) != 0;      // (16-bit C: rounded by the store itself)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
@@ -142,6 +168,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     int vB[4], vA[4];
     __amdgpu_buffer_rsrc_t rB, rA;
     long brow0 = 0;
+    const uint16_t *kbaseA = nullptr, *kbaseB = nullptr;     // k-major operands: first element of the tile's k-row 0
     const bool loader = !SPEC || w < 4;
     bool edge = false;                                  // SPEC: the tile touches the matrix edge (rows clamped piece by piece)
     int eb0 = 0, ea0 = 0;
@@ -170,12 +197,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);       // logical k-chunk stored at this physical slot
             int rb = t.b0 + row; rb = (rb < N ? rb : N - 1) - t.b0; // clamp: rows past the edge are loaded, never stored
             int ra = t.a0 + row; ra = (ra < M ? ra : M - 1) - t.a0;
-            vB[i] = (int)(((long)rb * ldb + chunk * 8) * 2);
-            vA[i] = (int)(((long)ra * lda + chunk * 8) * 2);
+            // k-major: the lane's slot of piece i * 8 + w is (k-row 2 * piece + lane / 32, physical chunk lane % 32); columns past
+            // the edge read the tile's first chunk instead (M / N % 8 == 0: a chunk is inside or outside as a whole)
+            const int kin = 2 * (i * 8 + w) + (lane >> 5);
+            const int kchunk = (lane & 31) ^ (km_f(kin) << 1);
+            if constexpr (KMB) { const int c = t.b0 + kchunk * 8 < N ? kchunk * 8 : 0; vB[i] = (int)(((long)kin * ldb + c) * 2); }
+            else vB[i] = (int)(((long)rb * ldb + chunk * 8) * 2);
+            if constexpr (KMA) { const int c = t.a0 + kchunk * 8 < M ? kchunk * 8 : 0; vA[i] = (int)(((long)kin * lda + c) * 2); }
+            else vA[i] = (int)(((long)ra * lda + chunk * 8) * 2);
         }
-        brow0 = (long)t.b0 * ldb;
-        rA = rsrc(A0 + ((!is_select(EPI) && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (long)t.a0 * lda);
-        rB = rsrc(((!is_select(EPI) && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0);
+        brow0 = KMB ? (long)t.b0 : (long)t.b0 * ldb;
+        const uint16_t* ap = A0 + ((!is_select(EPI) && grp) ? grp[t.batch].aoff : (long)t.batch * sA) + (KMA ? (long)t.a0 : (long)t.a0 * lda);
+        const uint16_t* bp = ((!is_select(EPI) && grp) ? grp[t.batch].b : B0 + (long)t.batch * sB) + brow0;
+        if constexpr (KMA || KMB) { kbaseA = ap; kbaseB = bp; }
+        else { rA = rsrc(ap); rB = rsrc(bp); }
     };
     typedef __attribute__((address_space(3))) void lds_void;
     auto stage = [&](int buf, int kt) {
@@ -209,6 +244,25 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             }
             return;
         }
+        if constexpr (KMA || KMB) {
+            // k-major operand: the descriptor is rebased to the k-tile's first k-row (a scalar offset of kt * 64 rows can pass
+            // 2^31 bytes); k-rows at or past K (last k-tile, K % 64 != 0) aim out of range and land as zeros
+            const int kend = (kt == nk - 1 && K % TK != 0) ? K % TK : TK;
+            const int kl = lane >> 5;
+            const i32x4 wb = rsrc_words(KMB ? kbaseB + (long)kt * TK * ldb : kbaseB, (int)0x80000000u);
+            const i32x4 wa = rsrc_words(KMA ? kbaseA + (long)kt * TK * lda : kbaseA, (int)0x80000000u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = KMB ? (kl >= kend - 2 * (i * 8 + w) ? (int)0x80000000u : 0) : oob;
+                dma16(wb, base + (i * 8 + w) * 1024, vB[i] | o, KMB ? 0 : kt * (TK * 2));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = KMA ? (kl >= kend - 2 * (i * 8 + w) ? (int)0x80000000u : 0) : oob;
+                dma16(wa, base + OP_BYTES + (i * 8 + w) * 1024, vA[i] | o, KMA ? 0 : kt * (TK * 2));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + (i * 8 + w) * 1024), 16, vB[i] | oob, sob, 0, 0);
@@ -222,6 +276,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
     // a pending load makes the compiler put a full vmcnt(0) in front of every store of the epilogue.
     auto stage_bias = [&](const Tile& t, int slot) {
         if (bias0 && w == 0) {
+            if constexpr (KMA || KMB) {
+                dma16(rsrc_words(bias0 + (long)t.batch * sBias, N * 4), nt_smem + BIAS_BASE + slot * 1024, lane * 16, t.b0 * 4);
+                return;
+            }
             __amdgpu_buffer_rsrc_t r =     // (not const: a const-qualified resource makes the host pass drop the kernel stub silently)
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias0 + (long)t.batch * sBias), 0, N * 4, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(nt_smem + BIAS_BASE + slot * 1024), 16, (int)((t.b0 + lane * 4) * 4), 0, 0, 0);
@@ -236,6 +294,25 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
         offB[ks] = (wm * 128 + fr) * 128 + phys * 16;
         offA[ks] = OP_BYTES + (wn * 64 + fr) * 128 + phys * 16;
     }
+
+    // k-major operand: this lane's address for the transposed reads — lane 4q + p of a 16-lane group supplies k-row
+    // fq * 8 + q, columns 4p .. 4p + 3 of the fragment's 16; fragment j of the wave = 32-byte pair (wave's first pair + j), XORed in
+    // by the loaders below; + ks * 16 KiB for the k-half, + 2 KiB for the second four k-rows
+    int trB = 0, trA = 0;
+    {
+        const int q = fr >> 2, p = fr & 3, f = q | ((fq & 1) << 2);
+        const int in_pair = ((p >> 1) << 4) + ((p & 1) << 3);
+        trB = (fq * 8 + q) * 512 + (((wm * 8) ^ f) << 5) + in_pair;
+        trA = OP_BYTES + (fq * 8 + q) * 512 + (((wn * 4) ^ f) << 5) + in_pair;
+    }
+    auto tr8 = [](const unsigned char* p) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 2048));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
 
     bool stores_after_prefetch = false;
     int vb = blockIdx.x;
@@ -267,8 +344,22 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
             // are complete, this buffer is free), the k-tile after next is staged into this buffer, and the reads of the
             // next k-tile's first groups go out under the last 16 MFMAs of this one.
             bf16x8 fa[2][4], fb[8];
-            auto ldA = [&](const unsigned char* b, int ks, int n) { return *reinterpret_cast<const bf16x8*>(b + offA[ks] + n * 2048); };
-            auto ldB = [&](const unsigned char* b, int ks, int m) { return *reinterpret_cast<const bf16x8*>(b + offB[ks] + m * 2048); };
+            // (k-major: the fragment's pair index and the staging buffer's offset are XORed into the lane's address as ONE scalar the
+            // compiler cannot take apart — left alone it keeps the twelve lane addresses `tr ^ (j << 5)` in registers over the loop,
+            // and the instantiation spills; a spill reload in the tile transition waits, in order, behind the DMA prefetch)
+            auto km_at = [&](const unsigned char* b, int tr, int j, int ks) {
+                int u = (int)(b - nt_smem) | (j << 5);
+                asm volatile("" : "+s"(u));
+                return nt_smem + ((tr ^ u) + ks * 16384);
+            };
+            auto ldA = [&](const unsigned char* b, int ks, int n) {
+                if constexpr (KMA) return tr8(km_at(b, trA, n, ks));
+                else return *reinterpret_cast<const bf16x8*>(b + offA[ks] + n * 2048);
+            };
+            auto ldB = [&](const unsigned char* b, int ks, int m) {
+                if constexpr (KMB) return tr8(km_at(b, trB, m, ks));
+                else return *reinterpret_cast<const bf16x8*>(b + offB[ks] + m * 2048);
+            };
             if (nk > 1) stage(1, 1);
 #pragma unroll
             for (int n = 0; n < 4; ++n) fa[0][n] = ldA(nt_smem, 0, n);
@@ -286,7 +377,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_kernel(const uint16_t* __res
 #pragma unroll
                             for (int n = 0; n < 4; ++n) fa[1][n] = ldA(base, 1, n);
                         }
-                        fb[r & 7] = ldB(base, r >> 3, r & 7);
+                        // (k-major instantiations: the compiler drains every LDS read at the head of the k-tile loop — lgkmcnt(0)
+                        // where the k-contiguous form gets the exact count —, so group 0 issues no read in front of that wait and
+                        // group 1 issues two fragments)
+                        if (!((KMA || KMB) && s == 0)) {
+                            if ((KMA || KMB) && s == 1) fb[(r - 1) & 7] = ldB(base, (r - 1) >> 3, (r - 1) & 7);
+                            fb[r & 7] = ldB(base, r >> 3, r & 7);
+                        }
                     } else if (!LAST) {
                         if (r == 16) {
                             if ((diag & 4) || !loader) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (storers hold no DMA piece; ablation 4: no wait for the DMA — wrong results)
@@ -625,13 +722,16 @@ CLT_DEFINE_TU_STATE_SETTER(clt_internal_set_state_gemm_nt)
 // to the generic kernel), or a negative error.
 int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
                               int batch, long sA, long sB, long sC, const float* bias, long sBias, int accumulate,
-                              hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16) {
+                              hipStream_t st, const uint16_t* const* Bseg, int kts, const void* groups, bool out16, int km) {
     const GemmGroup* grp = static_cast<const GemmGroup*>(groups);
+    // km: bit 0 = A is k-major ([K][M], row stride lda), bit 1 = B is k-major ([K][N], row stride ldb)
+    const bool kma = km & 1, kmb = km & 2;
+    if (km && (out16 || Bseg || (kma && M % 8) || (kmb && N % 8))) return 1;
     // bf16 result (C is then a bf16 array; ldc / sC in bf16 elements): 8-column alignment, no accumulate, no groups
     if (out16 && ((accumulate & CLT_GEMM_ACCUMULATE) || grp || N % 8 || ldc % 8 || sC % 8)) return 1;
     const bool ok = K % 8 == 0 && (!Bseg || (K % TK == 0 && kts > 0)) && N % 4 == 0 && ldc % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0 &&
                     sC % 4 == 0 && sBias % 4 == 0 && aligned16(A) && (Bseg || grp || aligned16(B)) && (grp || aligned16(C)) && (!bias || aligned16(bias)) &&
-                    (long)M * N >= 256L * 256L && dma_offsets_fit(lda, ldb, K);
+                    (long)M * N >= 256L * 256L && dma_offsets_fit(kma ? 0 : lda, kmb ? 0 : ldb, K) && lda < (1L << 23) && ldb < (1L << 23);
     if (!ok) return 1;
     const int tilesA = (M + TA - 1) / TA, tilesB = (N + TB - 1) / TB;
     const long nblk = (long)tilesA * tilesB * batch;
@@ -648,6 +748,17 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
     } while (0)
     const bool spec = g_nt_variant == 2 || (g_nt_variant == 0 && K >= 2048 && K <= 8192);
     const bool f16 = clt_host_state.fp16 != 0;
+#define NT_GOK(F16_, KMA_, KMB_)                                                                                               \
+    do {                                                                                                                        \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<0, F16_, false, KMA_, KMB_>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return CLT_ERR_LAUNCH;    \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<0, F16_, false, KMA_, KMB_>), dim3(grid), dim3(512), LDS_BYTES, st, A, B, C, M, N, K, lda, ldb, \
+                           ldc, sA, sB, sC, bias, sBias, accumulate, tilesA, tilesB, (int)nblk, diag, SelEpi{}, Bseg, kts, grp);  \
+    } while (0)
+    if (km) {
+        if (f16) { if (kma && kmb) NT_GOK(true, true, true); else if (kmb) NT_GOK(true, false, true); else NT_GOK(true, true, false); }
+        else { if (kma && kmb) NT_GOK(false, true, true); else if (kmb) NT_GOK(false, false, true); else NT_GOK(false, true, false); }
+    } else
     if (out16) {
         if (f16) { if (spec) NT_GO(2, true, true); else NT_GO(2, true, false); }
         else { if (spec) NT_GO(2, false, true); else NT_GO(2, false, false); }
@@ -656,6 +767,7 @@ int clt_internal_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, float* C, in
         else { if (spec) NT_GO(0, false, true); else NT_GO(0, false, false); }
     }
 #undef NT_GO
+#undef NT_GOK
     CLT_LAUNCH_CHECK();
     return CLT_OK;
 }
@@ -690,10 +802,10 @@ extern "C" int clt_gemm_bf16_nt_kseg_out16(const uint16_t* A, const uint16_t* co
 // Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
 // groups: DEVICE array of {long aoff (elements); const uint16_t* B; float* C} records (all 16-byte aligned).
 extern "C" int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, int ngroups, int M, int N, int K, long lda, long ldb,
-                                        long ldc, void* stream) {
+                                        long ldc, int kmajor, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || ngroups <= 0 || !A || !groups) return CLT_ERR_SHAPE;
     return clt_internal_gemm_nt_bf16(A, nullptr, nullptr, M, N, K, lda, ldb, ldc, ngroups, 0, 0, 0, nullptr, 0, 0, as_stream(stream), nullptr, 0,
-                                     groups);
+                                     groups, false, kmajor & 3);
 }
 
 // C is never written: candidates (key >= ctl[seg].lb) go to the selection workspace.  ldc / sC only define the flat

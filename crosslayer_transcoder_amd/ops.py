@@ -417,13 +417,75 @@ def transpose_cast_2d(x: torch.Tensor) -> torch.Tensor:
     return cast_transpose_bf16(x.reshape(1, rows, -1))[0]
 
 
+#: the last round of a persistent batched GEMM with a long contraction, when it is short: its problems go through a second,
+#: grouped launch with the contraction cut in pieces (see _tail_split); CLT_AB=gemm_tail_split=0: one launch
+GEMM_TAIL_SPLIT = bool(ab_switch("gemm_tail_split", 1))
+_cus = {}
+
+
+def _persistent_blocks(device) -> int:
+    """Blocks of the persistent NT GEMM's grid: one per CU, a multiple of 8 (gemm_nt_bf16.hip: persistent_grid)."""
+    key = torch.device(device).index or 0
+    if key not in _cus:
+        n = torch.cuda.get_device_properties(device).multi_processor_count
+        _cus[key] = n // 8 * 8 if n >= 8 else 8
+    return _cus[key]
+
+
+def _tail_split(items: int, tiles: int, K: int, blocks: int) -> Tuple[int, int]:
+    """One persistent block per CU walks 256 x 256 tiles, so `items` batched problems of `tiles` tiles each take
+    ceil(items * tiles / blocks) rounds of K / 64 k-tiles — 576 tiles on 256 CUs pay 3 rounds for 2.25.  (t, s): the last t
+    problems leave the batched launch and run as t * s problems of a grouped launch, each over K / s of the contraction
+    (ceil(t * tiles * s / blocks) rounds of 1 / s the length) into fp32 slabs that clt_sum_slabs_f32 adds in piece order.
+    (0, 1): no split pays.  Priced in rounds of the whole contraction, as measured at K = 32768 (853 us per round): a piece
+    keeps >= 2048 of the contraction, a piece's tile costs 3 % of a round beyond its k-tiles (prologue + a 256 KB fp32 tile
+    stored while every other CU stores one: 23 us), a problem's slab sum 2 %; the estimate has to beat the one launch by 10 %
+    (B = 4096, d = 768, K = 32768 x 12 layers: 2.56 -> 1.73 + 0.39 + 0.07 ms, B = 2048: step 11.8 -> 11.1-11.4 ms; B = 1024 with its
+    144 tiles and B = 8192 with 4.5 rounds, estimated at 7 %, measured equal or slower: left alone)."""
+    plain = -(-items * tiles // blocks)
+    best, pick = 0.90 * plain, (0, 1)
+    for t in range(1, items + 1):
+        main = -(-(items - t) * tiles // blocks)
+        for s in (2, 3, 4, 6, 8, 12, 16):
+            if K % (128 * s) or K // s < 2048:
+                continue
+            est = main + -(-t * tiles * s // blocks) * (1.0 / s + 0.03) + 0.02 * t
+            if est < best - 1e-9:
+                best, pick = est, (t, s)
+    return pick
+
+
 def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
     """fo: bf16 [B, L, F]; WT: bf16 [L, d, F] (transposed weights)."""
     Bn, L, F = fo.shape
     d = WT.shape[1]
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
-    _gemm("clt_gemm_bf16", _chk(fo, op16()), 0, _chk(WT, op16()), 0, r, 0, Bn, d, F, L * F, F, L * d, False, True,
-          batch=L, sA=F, sB=d * F, sC=d, bias=b, sBias=d)
+    _chk(fo, op16()); _chk(WT, op16())
+    t, s = 0, 1
+    if GEMM_TAIL_SPLIT and F % 8 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
+        t, s = _tail_split(L, -(-Bn // 256) * -(-d // 256), F, _persistent_blocks(fo.device))
+    if t:
+        # the last t layers: s pieces of the feature contraction each, one fp32 slab per piece
+        Kp, slab_b = F // s, 4 * Bn * d
+        slabs = torch.empty(t * s, Bn, d, dtype=torch.float32, device=fo.device)
+        rec = []
+        for i in range(t):
+            l = L - t + i
+            for j in range(s):
+                rec += [l * F + j * Kp, WT.data_ptr() + 2 * (l * d * F + j * Kp), slabs.data_ptr() + (i * s + j) * slab_b]
+        table = _device_table(rec, fo.device)
+    if L - t:
+        _gemm("clt_gemm_bf16", fo, 0, WT, 0, r, 0, Bn, d, F, L * F, F, L * d, False, True,
+              batch=L - t, sA=F, sB=d * F, sC=d, bias=b, sBias=d)
+    if t:
+        rc = _timed_raw("gemm", 2.0 * Bn * d * F * t, "clt_gemm_bf16_nt_grouped", fo.data_ptr(), table.data_ptr(), t * s, Bn, d, Kp,
+                        L * F, F, d, 0, _stream())
+        if rc != 0:
+            raise CltError("clt_gemm_bf16_nt_grouped", rc)
+        for i in range(t):
+            l = L - t + i
+            call("clt_sum_slabs_f32", slabs.data_ptr() + i * s * slab_b, s, Bn * d, Bn, d, L * d,
+                 (b.data_ptr() + 4 * l * d) if b is not None else None, r.data_ptr() + 4 * l * d, _stream())
     return r
 
 
@@ -456,7 +518,7 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
                     p += 1
             table = _device_table(rec, fo.device)
             rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, op16()).data_ptr(),
-                            table.data_ptr(), P, Bn, d, F, L * F, F, d, _stream())
+                            table.data_ptr(), P, Bn, d, F, L * F, F, d, 0, _stream())
             if rc == 1 and l0 == 0:
                 ok = False
                 break
@@ -505,7 +567,7 @@ def clt_wgrad_t_grouped(fT: torch.Tensor, gT: torch.Tensor, outs: List[torch.Ten
     table = _device_table(rec, fT.device)
     P = L * (L + 1) // 2
     rc = _timed_raw("gemm", 2.0 * F * d * Bn * P, "clt_gemm_bf16_nt_grouped", fT.data_ptr(), table.data_ptr(), P, F, d, Bn, Bn, Bn, d,
-                    _stream())
+                    0, _stream())
     if rc == 1:
         return False
     if rc != 0:

@@ -55,6 +55,11 @@ int clt_destandardize_f32(const float* r_in, const float* mean, const float* std
  *   transB = 0: B stored [K][N] (ldb >= N);   1: B stored [N][K] (ldb >= K)
  * `batch` problems at element strides sA/sB/sC/sBias.  bias may be NULL.  accumulate != 0: C += .
  * f32: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the parity path (rtol 1e-5 vs the fp32 reference).
+ * bf16, which kernel: shapes with M*N >= 256^2 and 8-element alignment go through the persistent LDS-DMA kernel
+ *       (gemm_nt_bf16.hip) in every layout — k-contiguous operands (transA = 0, transB = 1) staged as they lie, k-major ones
+ *       (transA = 1: A as [K][M]; transB = 0: B as [K][N]) through transposed LDS reads, same k order per element in all four
+ *       forms (bit-identical results; the k-major forms run 5-15 % slower, profiles/r03_gemm_ab.md section 11); anything else
+ *       through the generic tile kernel.
  * bf16: bf16 operands (uint16_t), fp32 accumulate and fp32 C  (v_mfma_f32_32x32x16_bf16).
  *       `accumulate` is a flag word there: bit 0 (CLT_GEMM_ACCUMULATE) C +=; bit 1 (CLT_GEMM_ROUND_ACC): the product is
  *       rounded to the 16-bit operand format BEFORE the fp32 bias is added — torch.autocast's order for the encoder
@@ -369,9 +374,12 @@ int clt_gemm_nt_grid_limit(int blocks);
 /* Grouped NT GEMM: ngroups problems of one shape in ONE persistent launch, C_g[M][N] = (A + aoff_g)[M][K] * B_g[N][K]^T.
  * groups: DEVICE array of records {int64 aoff (elements into A); const uint16_t* B; float* C}.  Used for the dense
  * cross-layer decoder forward (clt.py:334-343): all (target layer, source layer) pairs — 78 at L = 12 — fill the chip
- * together instead of 12 launches of 48..576 tiles.  Returns 1 when the shape does not qualify. */
+ * together instead of 12 launches of 48..576 tiles.  kmajor: bit 0 = every A_g is stored [K][M] (row stride lda), bit 1 = every
+ * B_g is stored [K][N] (row stride ldb) — the operand as it lies when the contraction runs over the outer index of a row-major
+ * tensor (decoder forward from the [F][d] weights, weight gradients from [B][F] features and [B][d] gradients): no transposed
+ * copy is made, the kernel transposes in its LDS reads.  Returns 1 when the shape does not qualify. */
 int clt_gemm_bf16_nt_grouped(const uint16_t* A, const void* groups, int ngroups, int M, int N, int K, long lda, long ldb,
-                             long ldc, void* stream);
+                             long ldc, int kmajor, void* stream);
 /* Encoder GEMM fused with the candidate filter of the batch-mode selection (bf16 NT fast kernel only; returns 1 when
  * the shape does not qualify): C = A[M][K] * B[N][K]^T + bias is NOT stored; every element whose key is >= the lower
  * bound of its segment is appended to the candidate list of a selection workspace prepared by stage 0 of

@@ -603,6 +603,38 @@ def test_gemm_nt_fast_path(ops, Bn, L, d, F):
     assert torch.equal(out.cpu().reshape(n, n), Bm.float().T)
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(512, 256, 512, 1), (264, 520, 200, 2), (768, 256, 4096, 1), (256, 264, 72, 3),
+                                          (1032, 768, 130 * 8, 1)])
+def test_gemm_k_major_operands(ops, M, N, K, batch):
+    """The LDS-DMA kernel with k-major operands (A stored [K][M] and / or B stored [K][N]: transposed LDS reads instead of
+    transposed copies) — every combination against the fp64 product of the same bf16 operands: edge tiles in M and N, a k tail,
+    batches, bias, accumulate, and the A = I layout check."""
+    bf = torch.bfloat16
+    A = _rand(batch, M, K, seed=1, scale=K ** -0.5).to(bf)
+    B = _rand(batch, K, N, seed=2).to(bf)
+    bias = _rand(batch, N, seed=3, scale=0.1)
+    want = torch.bmm(A.double(), B.double()) + bias.double()[:, None]
+    for tA in (False, True):
+        for tB in (False, True):
+            a = (A.transpose(1, 2) if tA else A).contiguous().to(DEV)           # tA: stored [K][M]
+            b = (B.transpose(1, 2) if tB else B).contiguous().to(DEV)           # tB: stored [N][K]
+            out = torch.full((batch, M, N), float("nan"), device=DEV)
+            for rep in range(2):
+                ops._gemm("clt_gemm_bf16", a, 0, b, 0, out, 0, M, N, K, M if tA else K, K if tB else N, N, tA, tB, batch=batch,
+                          sA=M * K, sB=K * N, sC=M * N, bias=bias.to(DEV), sBias=N, accumulate=rep == 1)
+            assert_close(out, 2 * want, **tol(want, 4e-6), what=f"transA={tA} transB={tB}")
+    n = 256
+    Bm = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(bf)   # exactly representable, asymmetric
+    eye = torch.eye(n).to(bf).to(DEV)
+    for tA, tB, want in ((False, False, Bm.float()), (True, False, Bm.float()), (True, True, Bm.float().T)):
+        out = torch.empty(n, n, device=DEV)
+        ops._gemm("clt_gemm_bf16", eye, 0, Bm.to(DEV), 0, out, 0, n, n, n, n, n, n, tA, tB)
+        assert torch.equal(out.cpu(), want), (tA, tB)
+        out = torch.empty(n, n, device=DEV)                                    # ... and with the asymmetric matrix as A
+        ops._gemm("clt_gemm_bf16", Bm.to(DEV), 0, eye, 0, out, 0, n, n, n, n, n, n, tA, tB)
+        assert torch.equal(out.cpu(), Bm.float().T if tA else Bm.float()), (tA, tB, "A")
+
+
 @pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4)])
 def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
     """clt_jumprelu_fwd_bf16 / clt_jumprelu_loss_bwd_bf16 against the separate fp32 passes + casts (ragged tiles:
@@ -683,6 +715,39 @@ def test_clt_decoder_fwd_grouped_launches(ops, monkeypatch):
             want[:, l] += fd[:, lp] @ WTs[l][lp].double().cpu().T
         want[:, l] += bias[l].double().cpu()
     assert torch.allclose(one.double().cpu(), want, rtol=1e-4, atol=1e-3)
+
+
+def test_plt_decoder_fwd_tail_split(ops, monkeypatch):
+    """Per-layer decoder forward (K = features): the short last round of the persistent batched GEMM as a grouped launch over
+    pieces of the contraction + slab sums — against the one-launch form and an fp64 reference; the split it picks at the
+    benchmark's shapes."""
+    assert ops._tail_split(12, 48, 32768, 256) == (2, 8)            # B 4096, d 768: 576 tiles = 2.25 rounds -> 2 + 3/8
+    assert ops._tail_split(12, 24, 32768, 256) == (2, 16)           # B 2048: 1.125 rounds -> 1 + 3/16
+    assert ops._tail_split(12, 96, 32768, 256) == (0, 1)            # B 8192: 4.5 rounds of 5, estimate within 10 %
+    assert ops._tail_split(12, 128, 32768, 256) == (0, 1)           # whole rounds: nothing to gain
+    assert ops._tail_split(12, 48, 768, 256) == (0, 1)              # short contraction: no pieces
+    B, L, d, F = 512, 3, 256, 8192                                  # 2 tiles per layer
+    gen = torch.Generator().manual_seed(34)
+    feat = torch.relu(torch.randn(B, L, F, generator=gen)).cuda()
+    W = (torch.rand(L, F, d, generator=gen) * 2 - 1).cuda()
+    bias = torch.randn(L, d, generator=gen).cuda()
+    fo, WT = ops.cast_bf16(feat), ops.cast_transpose_bf16(W.contiguous())
+    picks = []
+    real = ops._tail_split
+    monkeypatch.setattr(ops, "_tail_split", lambda *a: picks.append(real(*a)) or picks[-1])
+    split = ops.plt_decoder_fwd_t(fo, WT, bias)
+    assert picks[-1][0] > 0 and picks[-1][1] > 1                    # (6 tiles on 256 CUs: every layer is cut)
+    monkeypatch.setattr(ops, "_tail_split", lambda *a: (1, 2))      # a mixed launch: two layers batched, one cut in two
+    mixed = ops.plt_decoder_fwd_t(fo, WT, bias)
+    monkeypatch.setattr(ops, "GEMM_TAIL_SPLIT", False)
+    one = ops.plt_decoder_fwd_t(fo, WT, bias)
+    want = torch.einsum("blf,ldf->bld", fo.double().cpu(), WT.double().cpu()) + bias.double().cpu()
+    for got in (split, mixed, one):
+        assert torch.allclose(got.double().cpu(), want, rtol=1e-4, atol=2e-3)
+    assert torch.equal(mixed[:, :2], one[:, :2])
+    # without a bias
+    monkeypatch.setattr(ops, "GEMM_TAIL_SPLIT", True)
+    assert torch.allclose(ops.plt_decoder_fwd_t(fo, WT, None).double().cpu(), want - bias.double().cpu(), rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("nb,rows,n", [(3, 200, 768), (1, 64, 256), (2, 1000, 108)])
