@@ -493,15 +493,16 @@ def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
 GROUPED_SLAB_BYTES = 4 << 30
 
 
-def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Tensor:
+def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b, k_major: bool = False) -> torch.Tensor:
     """fo: bf16 [B, L, F]; WTs[l]: bf16 [(l+1), d, F].  Per target layer one batched GEMM over its source layers
-    (split-K by source layer) into fp32 slabs, summed in source-layer order (+ bias)."""
+    (split-K by source layer) into fp32 slabs, summed in source-layer order (+ bias).  k_major: WTs[l] is the weight as it
+    lies, bf16 [(l+1), F, d] — the grouped launch takes it as a k-major B operand (no transposed copy; same bits)."""
     Bn, L, F = fo.shape
-    d = WTs[0].shape[1]
+    d = WTs[0].shape[2 if k_major else 1]
     r = torch.empty(Bn, L, d, dtype=torch.float32, device=fo.device)
     # (target, source) pairs in persistent grouped launches, one fp32 slab per pair; consecutive target layers share a
     # launch as long as their slabs fit GROUPED_SLAB_BYTES (G32: all 78 pairs, 1 GB, one launch)
-    if F % 8 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
+    if F % 8 == 0 and d % (8 if k_major else 4) == 0 and Bn * d >= 256 * 256:
         slab_b = 4 * Bn * d
         l0, ok = 0, True
         while l0 < L and ok:
@@ -518,7 +519,7 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
                     p += 1
             table = _device_table(rec, fo.device)
             rc = _timed_raw("gemm", 2.0 * Bn * d * F * P, "clt_gemm_bf16_nt_grouped", _chk(fo, op16()).data_ptr(),
-                            table.data_ptr(), P, Bn, d, F, L * F, F, d, 0, _stream())
+                            table.data_ptr(), P, Bn, d, F, L * F, d if k_major else F, d, 2 if k_major else 0, _stream())
             if rc == 1 and l0 == 0:
                 ok = False
                 break
@@ -534,8 +535,8 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b) -> torch.Ten
             return r
     slabs = torch.empty(L, Bn, d, dtype=torch.float32, device=fo.device)
     for l in range(L):
-        _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], op16()), 0, slabs, 0, Bn, d, F, L * F, F, d, False, True, batch=l + 1,
-              sA=F, sB=d * F, sC=Bn * d)
+        _gemm("clt_gemm_bf16", fo, 0, _chk(WTs[l], op16()), 0, slabs, 0, Bn, d, F, L * F, d if k_major else F, d, False, not k_major,
+              batch=l + 1, sA=F, sB=d * F, sC=Bn * d)
         call("clt_sum_slabs_f32", slabs.data_ptr(), l + 1, Bn * d, Bn, d, L * d, (b.data_ptr() + 4 * l * d) if b is not None else None,
              r.data_ptr() + 4 * l * d, _stream())
     return r

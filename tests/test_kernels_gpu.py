@@ -715,6 +715,11 @@ def test_clt_decoder_fwd_grouped_launches(ops, monkeypatch):
             want[:, l] += fd[:, lp] @ WTs[l][lp].double().cpu().T
         want[:, l] += bias[l].double().cpu()
     assert torch.allclose(one.double().cpu(), want, rtol=1e-4, atol=1e-3)
+    # the same from the weights as they lie ([F][d]: k-major B operand of the grouped launch): same bits
+    Wops = [ops.cast_bf16(w.contiguous()) for w in Ws]
+    assert torch.equal(ops.clt_decoder_fwd_t(fo, Wops, bias, k_major=True), many)
+    monkeypatch.setattr(ops, "GROUPED_SLAB_BYTES", 4 << 30)
+    assert torch.equal(ops.clt_decoder_fwd_t(fo, Wops, bias, k_major=True), one)
 
 
 def test_plt_decoder_fwd_tail_split(ops, monkeypatch):
