@@ -245,6 +245,9 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind, act16, monkeypa
         assert "pre_actvs" not in dict.keys(out) and out["pre_actvs"].dtype == torch.float32      # (lazy fp32 view of the bf16 tensor)
         pre_ref = ref["pre"]
         assert_close(out["pre_actvs"], pre_ref, 1e-2, 1e-2 * float(pre_ref.abs().max()), "bf16 pre-activations")
+        # (the lazy features come from the lazy pre-activations, through a weak reference to the output that holds both)
+        assert "features" not in dict.keys(out)
+        assert torch.equal(out["features"], ops_mod().jumprelu_fwd(out["pre_actvs"], mod.model.nonlinearity.theta.detach()))
     elif loss_kind == "jumprelu":
         # the fused tile passes (bf16 operands written directly) against the separate fp32 passes + casts: the forward GEMM
         # operands are bit-identical; the backward pass takes tanh from the hardware exp2 / rcp (about 1e-6 absolute), which can
@@ -267,6 +270,57 @@ def test_dense_bf16_fast_path_step(dec_kind, nl_kind, loss_kind, act16, monkeypa
         for k, g2 in out2["grads"].items():
             rel = float((out["grads"][k] - g2).norm() / (g2.norm() + 1e-12))
             assert rel < 1e-3, f"fused vs unfused grad {k}: rel l2 err {rel:.3g}"
+
+
+def ops_mod():
+    from crosslayer_transcoder_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("dec_kind,nl_kind,loss_kind", [("plt", "jumprelu", "jumprelu"), ("clt", "jumprelu", "jumprelu"), ("clt", "batchtopk", "base")])
+def test_steps_leave_no_reference_cycle_behind(dec_kind, nl_kind, loss_kind):
+    """With Python's cyclic collector off, the device memory in use does not grow from step to step: a step's output must not
+    sit in a reference cycle (one through its lazy `features` closure kept every step's gradients and 16-bit pre-activations
+    alive until the collector ran: +6 GB every few steps at B = 8192)."""
+    import gc
+    from crosslayer_transcoder_amd import precision
+    from tests.build_cases import build_module
+    B, L, d, F = 512, 3, 128, 512
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, d, generator=g)
+    batch = torch.stack([x, 0.5 * x + 0.1 * torch.randn(B, L, d, generator=g)], 1).cuda()
+    nl = {"jumprelu": {"kind": "jumprelu", "theta": 0.05, "bandwidth": 0.1}, "batchtopk": {"kind": "batchtopk", "k": 8, "e": 0.1}}[nl_kind]
+    lc = {"kind": "base"} if loss_kind == "base" else {"kind": "jumprelu", "lambda_sparsity": 0.05, "c_sparsity": 1.0, "use_tanh": True,
+                                                       "pre_actv_loss": 1e-3}
+    params = {"encoder.W": (torch.rand(L, d, F, generator=g) * 2 - 1) * F ** -0.5, "encoder.b": torch.zeros(L, F), "decoder.b": torch.zeros(L, d)}
+    if dec_kind == "clt":
+        for l in range(L):
+            params[f"decoder.W_{l}"] = (torch.rand(l + 1, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    else:
+        params["decoder.W"] = (torch.rand(L, F, d, generator=g) * 2 - 1) * (d * L) ** -0.5
+    if nl_kind == "jumprelu":
+        params["nonlinearity.theta"] = torch.full((1, L, F), 0.05)
+    case = {"cfg": {"decoder": dec_kind, "d_features": F, "nonlinearity": nl, "loss": lc}, "opt": {"lr": 1e-3}, "batches": batch[None].cpu(),
+            "init_params": params, "last_active0": torch.zeros(L, F, dtype=torch.long), "max_steps": 100}
+    mod = build_module(case)
+    mod.log_metrics_every = 0
+    mod.attach_optimizers()
+    with precision("bf16-mixed"):
+        for t in range(3):
+            mod.training_step(batch, t)
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        try:
+            used = []
+            for t in range(3, 7):
+                mod.training_step(batch, t)
+                torch.cuda.synchronize()
+                used.append(torch.cuda.memory_allocated())
+        finally:
+            gc.enable()
+    # (a few hundred bytes may come and go — a pointer table of new addresses, a counter —; one step's tensors are megabytes here)
+    assert max(used) - min(used) < (1 << 16), [u - used[0] for u in used]
 
 
 @pytest.mark.parametrize("nl_kind", ["batchtopk", "perlayerbatchtopk"])
