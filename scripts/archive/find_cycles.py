@@ -17,6 +17,10 @@ import crosslayer_transcoder_amd as cta  # noqa: E402
 args = bench.parse_args()
 cta.set_precision(args.precision)
 dev = torch.device("cuda:0")
+if args.shard_rehearsal:                       # (the sharded schedule through RCCL on one rank, as bench.py sets it up)
+    import torch.distributed as dist
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29523", rank=0, world_size=1, device_id=dev)
 mod = bench.build(args, dev)
 mod.attach_optimizers()
 A = bench.synth_target_map(args.layers, args.d_acts, dev)

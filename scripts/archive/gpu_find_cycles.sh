@@ -13,5 +13,5 @@ run() {
 }
 run headline --k 4 && run plt_jumprelu_dense --nonlinearity jumprelu --decoder plt && run clt_jumprelu_dense --nonlinearity jumprelu --decoder clt && \
 run clt_jumprelu_lists --nonlinearity jumprelu --decoder clt --theta 0.26 && run topk --nonlinearity topk --k 4 && run topk_aux --nonlinearity topk --aux --k 4 && \
-run fp32 --precision 32 --k 4 && run relu --nonlinearity relu && run fp16 --precision 16-mixed --k 4
+run fp32 --precision 32 --k 4 && run relu --nonlinearity relu && run fp16 --precision 16-mixed --k 4 && run shard_rehearsal --shard-rehearsal --k 4 && run shard_rehearsal_jumprelu --shard-rehearsal --nonlinearity jumprelu && run zipf --skew zipf --k 4
 cat gpurun_out/cycles.txt
