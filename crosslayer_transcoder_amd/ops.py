@@ -419,7 +419,7 @@ def transpose_cast_2d(x: torch.Tensor) -> torch.Tensor:
 
 #: the last round of a persistent batched GEMM with a long contraction, when it is short: its problems go through a second,
 #: grouped launch with the contraction cut in pieces (see _tail_split); CLT_AB=gemm_tail_split=0: one launch
-GEMM_TAIL_SPLIT = bool(ab_switch("gemm_tail_split", 1))
+GEMM_TAIL_SPLIT = ab_switch("gemm_tail_split", 1)             # (2: adopt a split the cost model prices at 5 % instead of 10 %, for A/B runs)
 _cus = {}
 
 
@@ -432,7 +432,7 @@ def _persistent_blocks(device) -> int:
     return _cus[key]
 
 
-def _tail_split(items: int, tiles: int, K: int, blocks: int) -> Tuple[int, int]:
+def _tail_split(items: int, tiles: int, K: int, blocks: int, gain: float = 0.10) -> Tuple[int, int]:
     """One persistent block per CU walks 256 x 256 tiles, so `items` batched problems of `tiles` tiles each take
     ceil(items * tiles / blocks) rounds of K / 64 k-tiles — 576 tiles on 256 CUs pay 3 rounds for 2.25.  (t, s): the last t
     problems leave the batched launch and run as t * s problems of a grouped launch, each over K / s of the contraction
@@ -443,7 +443,7 @@ def _tail_split(items: int, tiles: int, K: int, blocks: int) -> Tuple[int, int]:
     (B = 4096, d = 768, K = 32768 x 12 layers: 2.56 -> 1.73 + 0.39 + 0.07 ms, B = 2048: step 11.8 -> 11.1-11.4 ms; B = 1024 with its
     144 tiles and B = 8192 with 4.5 rounds, estimated at 7 %, measured equal or slower: left alone)."""
     plain = -(-items * tiles // blocks)
-    best, pick = 0.90 * plain, (0, 1)
+    best, pick = (1.0 - gain) * plain, (0, 1)
     for t in range(1, items + 1):
         main = -(-(items - t) * tiles // blocks)
         for s in (2, 3, 4, 6, 8, 12, 16):
@@ -463,7 +463,7 @@ def plt_decoder_fwd_t(fo: torch.Tensor, WT: torch.Tensor, b) -> torch.Tensor:
     _chk(fo, op16()); _chk(WT, op16())
     t, s = 0, 1
     if GEMM_TAIL_SPLIT and F % 8 == 0 and d % 4 == 0 and Bn * d >= 256 * 256:
-        t, s = _tail_split(L, -(-Bn // 256) * -(-d // 256), F, _persistent_blocks(fo.device))
+        t, s = _tail_split(L, -(-Bn // 256) * -(-d // 256), F, _persistent_blocks(fo.device), 0.05 if GEMM_TAIL_SPLIT == 2 else 0.10)
     if t:
         # the last t layers: s pieces of the feature contraction each, one fp32 slab per piece
         Kp, slab_b = F // s, 4 * Bn * d
