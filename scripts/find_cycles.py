@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reference cycles a training step leaves behind (they keep their tensors alive until Python's cyclic collector runs):
 a few steps with the collector off, then one collection with DEBUG_SAVEALL and a census of what it found.
-python scripts/archive/find_cycles.py <bench.py flags ...>"""
+python scripts/find_cycles.py <bench.py flags ...>"""
 import collections
 import gc
 import os
@@ -10,7 +10,7 @@ import types
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import crosslayer_transcoder_amd as cta  # noqa: E402
 

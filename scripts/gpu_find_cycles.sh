@@ -1,5 +1,5 @@
 #!/bin/bash
-# scripts/archive/find_cycles.py over the step's regimes at a small shape: allocation growth with the collector off, and the closures found in cycles
+# scripts/find_cycles.py over the step's regimes at a small shape: allocation growth with the collector off, and the closures found in cycles
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 run() {
   tag=$1; shift
   echo "## $tag: $*" >> gpurun_out/cycles.txt
-  timeout -k 10 200 python3 -u scripts/archive/find_cycles.py --features 2048 --batch 512 "$@" > gpurun_out/cycles_run.txt 2>&1 || { tail -20 gpurun_out/cycles_run.txt; exit 1; }
+  timeout -k 10 200 python3 -u scripts/find_cycles.py --features 2048 --batch 512 "$@" > gpurun_out/cycles_run.txt 2>&1 || { tail -20 gpurun_out/cycles_run.txt; exit 1; }
   grep "^step\|^collected\|^\[" gpurun_out/cycles_run.txt >> gpurun_out/cycles.txt
   grep "^function\|^object" gpurun_out/cycles_run.txt | grep -v memory_stats | sort | uniq -c >> gpurun_out/cycles.txt || true
 }

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Wall time of every training step of one bench configuration (synchronised per step): where do slow steps come from?
-python scripts/archive/step_times.py <steps> <bench.py flags ...>"""
+python scripts/step_times.py <steps> <bench.py flags ...>"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 steps = int(sys.argv[1])
 sys.argv = [sys.argv[0]] + sys.argv[2:]
 import bench  # noqa: E402
