@@ -201,3 +201,23 @@ def test_fp16_fused_step_advances_the_lightning_progress_hooks(monkeypatch):
         cta.set_precision("32")
     assert calls == ["before", "raw-step", "after"] * 3
     assert mod.loss_scaler.growth_tracker == 3 and mod.loss_scaler.skipped_steps == 0
+
+
+def test_tail_split_cost_model():
+    """ops._tail_split (host logic of the per-layer decoder forward): which of a persistent batched GEMM's problems leave the
+    launch for a grouped one over pieces of the contraction.  Pieces are whole pairs of k-tiles, keep 2048 of the contraction,
+    and a split is taken only where the model prices it 10 % (or the asked gain) below the one launch."""
+    from crosslayer_transcoder_amd import ops
+    assert ops._tail_split(12, 48, 32768, 256) == (2, 8)            # B 4096, d 768: 576 tiles = 2.25 rounds -> 2 + 3/8
+    assert ops._tail_split(12, 24, 32768, 256) == (2, 16)           # B 2048: 1.125 rounds -> 1 + 3/16
+    assert ops._tail_split(12, 96, 32768, 256) == (0, 1)            # B 8192: 4.5 rounds of 5, priced at 7 %
+    assert ops._tail_split(12, 96, 32768, 256, 0.05) == (4, 2)      # ... taken when 5 % is enough
+    assert ops._tail_split(12, 128, 32768, 256) == (0, 1)           # whole rounds: nothing to gain
+    assert ops._tail_split(12, 12, 32768, 256) == (0, 1)            # B 1024: the pieces' fixed costs eat the gain
+    assert ops._tail_split(12, 48, 768, 256) == (0, 1)              # short contraction: no pieces
+    assert ops._tail_split(12, 48, 10000, 256) == (0, 1)            # no piece count divides the contraction into pairs of k-tiles
+    for items, tiles, K, blocks in ((12, 48, 32768, 256), (7, 30, 16384, 304), (3, 2, 8192, 256), (16, 5, 65536, 64)):
+        t, s = ops._tail_split(items, tiles, K, blocks)
+        assert 0 <= t <= items and (t == 0) == (s == 1)
+        if t:
+            assert K % (128 * s) == 0 and K // s >= 2048
