@@ -3,7 +3,7 @@ run these sizes in seconds), in the style of tests/test_fullsize_gpu.py:
 
 * config 2 — PLT JumpReLU, GPT-2 small, L=12 d=768 F=32768/layer, B=4096, bf16;
 * config 4, one rank's share of the 8-way feature shard — CLT JumpReLU + pre-activation loss, Llama-3.2-1B shape
-  L=16 d=2048, F=8192/8 = 1024 features per layer and rank;
+  L=16 d=2048, F=8192/8 = 1024 features per layer and rank — and the whole F=8192 dictionary on one GPU;
 * config 5, one rank's share — CLT PerLayerTopK(16) + aux PerLayerTopK(512), Llama-3-8B shape L=32 d=4096, F = 1024 per rank.
 
 Properties: (1) every loss term equals a plain recomputation from the step's own pre-activations / reconstruction;
@@ -69,11 +69,14 @@ def _jumprelu_terms_from_outputs(mod, out, batch):
     return mse, lam * sparsity / B, mod.pre_actv_loss * pre_act / (B * L)
 
 
-@pytest.mark.parametrize("cfg", ["config2_plt_jumprelu", "config4_shard_clt_jumprelu"])
+@pytest.mark.parametrize("cfg", ["config2_plt_jumprelu", "config4_shard_clt_jumprelu", "config4_full_clt_jumprelu"])
 def test_jumprelu_configs_full_shape(cfg, monkeypatch):
     import crosslayer_transcoder_amd as cta
     from crosslayer_transcoder_amd import engine
-    shape = dict(decoder="plt") if cfg.startswith("config2") else dict(decoder="clt", layers=16, d_acts=2048, features=1024, shard_of=8)
+    # (config 4 twice: one rank's share of the 8-way feature shard, and the whole dictionary on one GPU — 80 GB at the peak)
+    shape = (dict(decoder="plt") if cfg.startswith("config2") else
+             dict(decoder="clt", layers=16, d_acts=2048, features=1024, shard_of=8) if "shard" in cfg else
+             dict(decoder="clt", layers=16, d_acts=2048, features=8192))
     try:
         # ---- dense regime at the configuration's own theta = 0.03 (about 45 % of the entries active) -------------------------
         mod, batches, a = _build(**shape)
