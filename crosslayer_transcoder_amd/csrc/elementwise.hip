@@ -617,13 +617,14 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
                     *reinterpret_cast<uint2*>(feat + (long)(row + e) * n + col) = make_uint2(pack16<F16>(f[e][0], f[e][1]), pack16<F16>(f[e][2], f[e][3]));
             }
             if (JF_WIDE) store_rowpair16<F16>(feat, row, n, col, tx, f[0], f[1], cin && row < rows, (n & 7) == 0);
-            ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
+            if (featT) ft_store_pair<F16>(tile, pr, tx, f[0], f[1]);
         }
     }
     if (cin) {                                         // fired[] is zeroed by the host wrapper; equal-value stores may race
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (any[k]) fired[col + k] = 1;
     }
+    if (!featT) return;                                // (featT == nullptr: the row-major copy alone — a consumer that takes the features k-major)
     __syncthreads();
     ft_write_transposed(tile, featT, c0, r0, rows, n);
 }
@@ -1294,7 +1295,7 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
 int clt_jumprelu_fwd_bf16(const void* x, int x_bf16, const float* theta, const float* bias, int rows, int n, uint16_t* feat,
                           uint16_t* featT, uint8_t* fired, void* st) {
     if (rows <= 0 || n <= 0) return CLT_ERR_SHAPE;
-    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || !aligned16(featT) || (theta && !aligned16(theta)) ||
+    if (rows % 8 || n % 4 || !aligned16(x) || !aligned16(feat) || (featT && !aligned16(featT)) || (theta && !aligned16(theta)) ||
         (bias && !aligned16(bias))) return CLT_ERR_ALIGN;
     if (hipMemsetAsync(fired, 0, (size_t)n, as_stream(st)) != hipSuccess) return CLT_ERR_LAUNCH;
     const dim3 grid((n + FT_C - 1) / FT_C, (rows + FT_R - 1) / FT_R);

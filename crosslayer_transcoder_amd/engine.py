@@ -88,6 +88,11 @@ class StepOutput(dict):
 #: (the bound from the last step did not hold: the step reran the unfused GEMM + selection)
 STATS = {"fused_select_steps": 0, "select_fallbacks": 0}
 
+#: dense 16-bit JumpReLU step of a per-layer decoder: the fused forward pass writes no transposed feature copy (a third of its
+#: bytes) and the decoder weight gradient reads the features as a k-major GEMM operand (ds_read_b64_tr_b16; 10 % slower than from
+#: the transposed copy, same bits): PLT JumpReLU step -0.5 ms.  Not for the cross-layer decoder, whose 78 weight-gradient pairs
+#: lose more than the pass gains (profiles/r03_gemm_ab.md section 11).  CLT_AB=km_wgrad_plt=0: transposed copy.
+KM_WGRAD_PLT = bool(ab_switch("km_wgrad_plt", 1))
 #: fuse the encoder GEMM with the BatchTopK candidate filter when last step's k-th value is known (bf16, base loss)
 FUSE_ENCODER_SELECT = True
 #: lower bound of the fused filter = SELECT_MARGIN * (last step's exact k-th value)
@@ -323,14 +328,20 @@ class _Decoder:
                 return df
         return ops.clt_decoder_dgrad(go, self.Wop) if self.clt else ops.plt_decoder_dgrad(go, self.Wop[0])
 
-    def wgrad(self, feat, g, grads: Dict[str, torch.Tensor], featT=None):
+    def wgrad(self, feat, g, grads: Dict[str, torch.Tensor], featT=None, feat_op=None):
         """grads[name] (+)= feat^T @ g; accumulates when the entry already exists.  featT: bf16 [L, F, B] when the
-        caller already has the transposed operand (then feat may be None)."""
+        caller already has the transposed operand (then feat may be None); feat_op (per-layer decoder): the 16-bit features
+        [B, L, F] as they lie — the GEMM takes them as its k-major A operand (same bits as through featT)."""
         Bn, d = g.shape[0], g.shape[2]
         L, F = self.L, self.dec.d_features
         if self.bf16:
-            fT = featT if featT is not None else ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
             gT = ops.transpose_cast_2d(g).view(L, d, Bn)             # [L, d, B]
+            if featT is None and feat_op is not None and not self.clt:
+                acc = "decoder.W" in grads
+                out = grads["decoder.W"] if acc else torch.empty(L, F, d, dtype=torch.float32, device=g.device)
+                grads["decoder.W"] = ops.wgrad_ta(feat_op, gT, out, acc)
+                return
+            fT = featT if featT is not None else ops.transpose_cast_2d(feat).view(L, F, Bn)          # [L, F, B]
             if self.clt and not any(f"decoder.W_{l}" in grads for l in range(L)):
                 outs = [torch.empty(l + 1, F, d, dtype=torch.float32, device=g.device) for l in range(L)]
                 if ops.clt_wgrad_t_grouped(fT, gT, outs):           # all (target, source) pairs in one persistent launch
@@ -832,7 +843,7 @@ def _backward_jumprelu(c, D, S, pre, pre_bias, theta, feat, fused_ops, fuse_jump
         D.sparse_wgrad(S, g, grads, optimizer, (dn, sq), g16)
         out["lists"] = S
     else:
-        D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None)
+        D.wgrad(feat, g, grads, featT=fused_ops[1] if fused_ops is not None else None, feat_op=fused_ops[0] if fused_ops is not None else None)
         D.add_norm_grads(dn, sq, grads, optimizer)
     grads["decoder.b"] = ops.column_sum(g)
     if theta is not None:
@@ -1122,7 +1133,8 @@ def _training_step(mod, batch: torch.Tensor, batch_idx: int, optimizer=None, spa
                 nl._kth_probe = ops.FlagProbe(S.used_fallback)        # (read at the next step, without blocking)
     elif fuse_jump:
         theta = nl.theta if isinstance(nl, JumpReLU) else None
-        fused_ops = ops.jumprelu_fwd_bf16(pre, theta, pre_bias)  # (feat bf16, feat^T bf16, fired)
+        # (feat bf16, feat^T bf16, fired); per-layer decoder: no transposed copy, its weight gradient takes the features k-major
+        fused_ops = ops.jumprelu_fwd_bf16(pre, theta, pre_bias, want_T=not (KM_WGRAD_PLT and not isinstance(dec, CrosslayerDecoder) and ops.wgrad_ta_ok(Bn, F, d)))
     elif isinstance(nl, JumpReLU):
         theta = nl.theta
         feat = ops.jumprelu_fwd(pre, theta)

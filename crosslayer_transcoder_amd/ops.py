@@ -542,6 +542,21 @@ def clt_decoder_fwd_t(fo: torch.Tensor, WTs: List[torch.Tensor], b, k_major: boo
     return r
 
 
+def wgrad_ta_ok(Bn: int, F: int, d: int) -> bool:
+    """Whether wgrad_ta's shape goes through the LDS-DMA kernel (else the generic tile kernel would take it: keep the copy)."""
+    return F % 8 == 0 and Bn % 8 == 0 and d % 4 == 0 and F * d >= 256 * 256
+
+
+def wgrad_ta(feat_op: torch.Tensor, gT: torch.Tensor, out: torch.Tensor, accumulate=False) -> torch.Tensor:
+    """Per-layer decoder weight gradient out[l] [F, d] (+)= feat[:, l]^T @ g[:, l] with the features as they lie: feat_op bf16
+    [B, L, F] is the k-major A operand (stored [K = B][M = F], row stride L * F), gT bf16 [L, d, B] the k-contiguous B."""
+    Bn, L, F = feat_op.shape
+    d = gT.shape[1]
+    _gemm("clt_gemm_bf16", _chk(feat_op, op16()), 0, _chk(gT, op16()), 0, out, 0, F, d, Bn, L * F, Bn, d, True, True,
+          batch=L, sA=F, sB=d * Bn, sC=F * d, accumulate=accumulate)
+    return out
+
+
 def wgrad_t(aT: torch.Tensor, bT: torch.Tensor, out: torch.Tensor, batch: int, sA: int, sB: int, accumulate=False):
     """out[i] [M, N] (+)= aT[i] [M, K] @ bT[i] [N, K]^T with K = tokens; aT/bT are the token-minor (transposed) bf16
     operands, e.g. features^T [L, F, B] and g^T [L, d, B]."""
@@ -828,10 +843,10 @@ def jumprelu_loss_bwd(pre, theta, sq, dfeat_main, bandwidth, lam_over_B, c, use_
     return sums, dpre, dth, dn
 
 
-def jumprelu_fwd_bf16(x, theta=None, bias=None):
+def jumprelu_fwd_bf16(x, theta=None, bias=None, want_T=True):
     """Dense bf16 regime: JumpReLU (theta=None: ReLU) straight to the GEMM operands.  x: fp32 or bf16 [B, L, F]; bias (fp32
     [L, F], optional) is added to x first (a 16-bit x then holds the encoder product alone: encoder_fwd_out16(..., None)).
-    Returns (feat bf16 [B, L, F], featT bf16 [L, F, B], fired uint8 [L, F])."""
+    Returns (feat bf16 [B, L, F], featT bf16 [L, F, B], fired uint8 [L, F]); want_T=False: no transposed copy (featT = None)."""
     _chk(x, x.dtype)
     if bias is not None:
         _chk(bias)
@@ -842,10 +857,10 @@ def jumprelu_fwd_bf16(x, theta=None, bias=None):
         _chk(theta)
         assert theta.numel() == L * F
     feat = torch.empty(Bn, L, F, dtype=op16(), device=x.device)
-    featT = torch.empty(L, F, Bn, dtype=op16(), device=x.device)
+    featT = torch.empty(L, F, Bn, dtype=op16(), device=x.device) if want_T else None
     fired = torch.empty(L, F, dtype=torch.uint8, device=x.device)
     call("clt_jumprelu_fwd_bf16", x.data_ptr(), int(x.dtype in _DT16), theta.data_ptr() if theta is not None else None,
-         bias.data_ptr() if bias is not None else None, Bn, L * F, feat.data_ptr(), featT.data_ptr(), fired.data_ptr(), _stream())
+         bias.data_ptr() if bias is not None else None, Bn, L * F, feat.data_ptr(), featT.data_ptr() if want_T else None, fired.data_ptr(), _stream())
     return feat, featT, fired
 
 

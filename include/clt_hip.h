@@ -203,7 +203,8 @@ int clt_jumprelu_loss_bwd_f32(const float* x, const float* theta, const float* s
  * and autograd do implicitly).  x: [rows][n] fp32 (rows = tokens, n = layers*features); rows % 8 == 0, n % 4 == 0,
  * 16-byte aligned pointers (else CLT_ERR_ALIGN: use the unfused entry points).
  *   clt_jumprelu_fwd_bf16:  feat[r][j] = bf16(jumprelu(x, theta)) ; featT[j][r] = the same, transposed ;
- *                           fired[j] = any_r feat > 0 (K12).  theta may be NULL (ReLU).  No fp32 feature tensor.
+ *                           fired[j] = any_r feat > 0 (K12).  theta may be NULL (ReLU).  No fp32 feature tensor.  featT may be
+ *                           NULL (a weight-gradient GEMM that takes the features k-major needs no transposed copy).
  *   clt_jumprelu_loss_bwd_bf16: the math of clt_jumprelu_loss_bwd_f32, but d(loss)/d(pre) leaves only as the transposed
  *                           bf16 GEMM operand dpreT[j][r] plus its fp32 column sums dbias[j] (encoder bias gradient). */
 /* x (and dfeat_main) may be held as bf16 (x_bf16 / dfeat_bf16 != 0): what clt_gemm_bf16_nt_out16 leaves.  bias (optional,

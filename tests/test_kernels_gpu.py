@@ -635,6 +635,24 @@ def test_gemm_k_major_operands(ops, M, N, K, batch):
         assert torch.equal(out.cpu(), Bm.float().T if tA else Bm.float()), (tA, tB, "A")
 
 
+@pytest.mark.parametrize("Bn,L,F,d", [(512, 3, 512, 128), (264, 2, 1032, 72)])
+def test_plt_weight_gradient_from_features_as_they_lie(ops, Bn, L, F, d):
+    """ops.wgrad_ta (the 16-bit features [B, L, F] as the k-major A operand of the per-layer decoder's weight-gradient GEMM)
+    gives the bits of ops.wgrad_t on the transposed copy, also accumulating; both against fp64."""
+    gen = torch.Generator().manual_seed(5)
+    feat = ops.cast_bf16(torch.relu(torch.randn(Bn, L, F, generator=gen)).cuda())
+    g = torch.randn(Bn, L, d, generator=gen).cuda()
+    gT = ops.transpose_cast_2d(g).view(L, d, Bn)
+    featT = feat.permute(1, 2, 0).contiguous()
+    assert ops.wgrad_ta_ok(Bn, F, d)
+    want = torch.einsum("blf,bld->lfd", feat.double().cpu(), gT.permute(2, 0, 1).double().cpu())
+    a = ops.wgrad_ta(feat, gT, torch.empty(L, F, d, device=DEV))
+    b = ops.wgrad_t(featT, gT, torch.empty(L, F, d, device=DEV), L, F * Bn, d * Bn)
+    assert torch.equal(a, b)
+    assert torch.allclose(a.double().cpu(), want, rtol=1e-4, atol=1e-3)
+    assert torch.equal(ops.wgrad_ta(feat, gT, a.clone(), True), ops.wgrad_t(featT, gT, b.clone(), L, F * Bn, d * Bn, True))
+
+
 @pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4)])
 def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
     """clt_jumprelu_fwd_bf16 / clt_jumprelu_loss_bwd_bf16 against the separate fp32 passes + casts (ragged tiles:
@@ -647,6 +665,8 @@ def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
     assert torch.equal(fb, ops.cast_bf16(feat))
     assert torch.equal(fT, ops.transpose_cast_2d(feat).view(L, F, rows))
     assert torch.equal(fired, ops.column_any_positive(feat))
+    fb1, fT1, fired1 = ops.jumprelu_fwd_bf16(x, theta, want_T=False)          # (no transposed copy: the same row-major copy and flags)
+    assert fT1 is None and torch.equal(fb1, fb) and torch.equal(fired1, fired)
     fb0, fT0, fired0 = ops.jumprelu_fwd_bf16(x, None)
     relu = ops.relu_fwd(x)
     assert torch.equal(fb0, ops.cast_bf16(relu)) and torch.equal(fT0, ops.transpose_cast_2d(relu).view(L, F, rows))
