@@ -624,7 +624,9 @@ __global__ __launch_bounds__(256) void jumprelu_fwd_bf16_kernel(const void* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (any[k]) fired[col + k] = 1;
     }
-    if (!featT) return;                                // (featT == nullptr: the row-major copy alone — a consumer that takes the features k-major)
+    // (featT == nullptr: the row-major copy alone, for a consumer that takes the features k-major.  A streaming form of that case —
+    // no tile, 8 columns per lane, 16-byte loads and stores — measured the same 1.20 ms for 3.2 GB read + 3.2 GB written)
+    if (!featT) return;
     __syncthreads();
     ft_write_transposed(tile, featT, c0, r0, rows, n);
 }

@@ -653,7 +653,7 @@ def test_plt_weight_gradient_from_features_as_they_lie(ops, Bn, L, F, d):
     assert torch.equal(ops.wgrad_ta(feat, gT, a.clone(), True), ops.wgrad_t(featT, gT, b.clone(), L, F * Bn, d * Bn, True))
 
 
-@pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4)])
+@pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4), (136, 2, 1100)])
 def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
     """clt_jumprelu_fwd_bf16 / clt_jumprelu_loss_bwd_bf16 against the separate fp32 passes + casts (ragged tiles:
     rows not a multiple of 64, columns not a multiple of 256)."""
@@ -665,8 +665,14 @@ def test_fused_dense_jumprelu_tile_passes(ops, rows, L, F):
     assert torch.equal(fb, ops.cast_bf16(feat))
     assert torch.equal(fT, ops.transpose_cast_2d(feat).view(L, F, rows))
     assert torch.equal(fired, ops.column_any_positive(feat))
-    fb1, fT1, fired1 = ops.jumprelu_fwd_bf16(x, theta, want_T=False)          # (no transposed copy: the same row-major copy and flags)
+    # no transposed copy: the same row-major copy and flags, fp32 and 16-bit x, with a bias
+    fb1, fT1, fired1 = ops.jumprelu_fwd_bf16(x, theta, want_T=False)
     assert fT1 is None and torch.equal(fb1, fb) and torch.equal(fired1, fired)
+    bias = torch.randn(L, F, generator=g).cuda()
+    x16 = ops.cast_bf16(x)
+    for xin in (x, x16):
+        a, b = ops.jumprelu_fwd_bf16(xin, theta, bias), ops.jumprelu_fwd_bf16(xin, theta, bias, want_T=False)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     fb0, fT0, fired0 = ops.jumprelu_fwd_bf16(x, None)
     relu = ops.relu_fwd(x)
     assert torch.equal(fb0, ops.cast_bf16(relu)) and torch.equal(fT0, ops.transpose_cast_2d(relu).view(L, F, rows))
