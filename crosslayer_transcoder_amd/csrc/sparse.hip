@@ -794,6 +794,35 @@ __global__ __launch_bounds__(TPB) void row_pass_hot_kernel(RowPassArgs a, RowPas
                 }
                 continue;
             }
+            if (pass == 0) {
+                // Not segmented (the segment table was full when hot_columns_kernel reached this column — which columns that hits
+                // depends on the order its atomics arrive in — or there is no scratch): the wave forms the SAME sums in the same
+                // order as the segment blocks would — a segment's HW pieces from zero each, added in piece order, the segments
+                // added in segment order — so a row's update does not depend on whether its column got slots.
+                constexpr int HW = HotWaves<NT>::value;
+#pragma unroll 1
+                for (uint32_t s0 = p0; s0 < p1; s0 += HOT_SEG) {
+                    const uint32_t s1 = min(p1, s0 + HOT_SEG), per = (s1 - s0 + HW - 1) / HW;
+                    float sg[NT][4], sc = 0.0f;
+#pragma unroll 1
+                    for (int w = 0; w < HW; ++w) {
+                        const uint32_t q0 = min(s1, s0 + (uint32_t)w * per), q1 = min(s1, q0 + per);
+                        float gp[NT][4], cp = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { gp[t][0] = 0.0f; gp[t][1] = 0.0f; gp[t][2] = 0.0f; gp[t][3] = 0.0f; }
+                        row_pass_walk<NT, true, 1, F16, HOT_HU>(a, 0, col, layer, lane, 0, 0, q0, q1, p0, wv, gp, cp, nullptr);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) sg[t][c] = w ? sg[t][c] + gp[t][c] : gp[t][c];
+                        sc = w ? sc + cp : cp;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { g[t][0] += sg[t][0]; g[t][1] += sg[t][1]; g[t][2] += sg[t][2]; g[t][3] += sg[t][3]; }
+                    csum += sc;
+                }
+                continue;
+            }
             row_pass_walk<NT, true, 1, F16>(a, pass, col, layer, lane, 0, 0, p0, p1, p0, wv, g, csum, nullptr);
         }
         row_pass_finish<NT, true, 1, F16, true>(a, r, col, lane, 0, 0, wv, g, mm, vv, csum);

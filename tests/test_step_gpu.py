@@ -823,3 +823,16 @@ def test_heavy_tailed_feature_frequencies_hot_rows(kind, prec, monkeypatch):
         rel = float((m - 0.1 * gfull).norm() / (0.1 * gfull.norm() + 1e-30))
         assert rel < (1e-2 if bf16 else 1e-4), f"{kind} {prec} fused exp_avg {k_}: rel l2 {rel:.3g}"
         assert float((p.detach().double() - params[k_].double().to(p.device)).abs().max()) <= 1.01e-3
+    # A segment table too small for every hot column (which columns get its slots depends on the order atomics arrive in): the
+    # rows without slots are walked by one wave in the segmented order, so the step's bits do not depend on the table's size
+    monkeypatch.setattr(ops, "HOT_SEG_SLOTS", 6)
+    mod3 = build_module(case)
+    mod3.log_metrics_every = 0
+    opt3, _ = mod3.attach_optimizers()
+    with precision(prec):
+        mod3.fused_train_step(batch.cuda(), 0, opt3)
+    cnt = mod3.last_step["lists"].hot[1]
+    assert int(cnt[1]) > 6, "the case must ask for more segments than the table holds"
+    for (k_, p), (_, p3) in zip(mod2.model.named_parameters(), mod3.model.named_parameters()):
+        assert torch.equal(p.detach(), p3.detach()), f"{kind} {prec} {k_}: segment table size changes the result"
+        assert torch.equal(opt.state[p]["exp_avg_sq"], opt3.state[p3]["exp_avg_sq"])
