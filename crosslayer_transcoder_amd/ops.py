@@ -1582,7 +1582,8 @@ def hot_columns(s: SparseLists):
     pinned memory behind the kernel and read a step later (it has long arrived: no stall), and a workload without hot columns
     pays for neither the extra launches of every row pass nor its skip test.  The row passes are correct with or without the
     list (a hot row then takes one wave); only the summation order of hot rows depends on it, and it is a deterministic
-    function of the previous step."""
+    function of the previous step.  (Within the hot-row form the order does not depend on the segment table's size: a column
+    that found no slots is summed by one wave in the segmented order.)"""
     hot = getattr(s, "hot", None)
     if hot is None and HOT_MIN_LEN > 0:
         dev = s.col_start.device
