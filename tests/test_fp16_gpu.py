@@ -49,7 +49,8 @@ def _oracle(case, scale, step_frac=0.5):
 
 
 @pytest.mark.parametrize("dec_kind,nl_kind,loss_kind,sparse", [("clt", "batchtopk", "base", True), ("clt", "batchtopk", "base", False),
-                                                               ("clt", "jumprelu", "jumprelu", False), ("plt", "relu", "base", None)])
+                                                               ("clt", "jumprelu", "jumprelu", False), ("plt", "relu", "base", None),
+                                                               ("plt", "jumprelu", "jumprelu", False)])
 def test_fp16_step_loss_and_gradients_vs_oracle(dec_kind, nl_kind, loss_kind, sparse):
     """Loss and every gradient (handed out carrying the loss scale, `out["grad_scale"]`) of one step in fp16 mode."""
     from crosslayer_transcoder_amd import precision
