@@ -635,22 +635,30 @@ def test_gemm_k_major_operands(ops, M, N, K, batch):
         assert torch.equal(out.cpu(), Bm.float().T if tA else Bm.float()), (tA, tB, "A")
 
 
+@pytest.mark.parametrize("prec", ["bf16-mixed", "16-mixed"])
 @pytest.mark.parametrize("Bn,L,F,d", [(512, 3, 512, 128), (264, 2, 1032, 72)])
-def test_plt_weight_gradient_from_features_as_they_lie(ops, Bn, L, F, d):
+def test_plt_weight_gradient_from_features_as_they_lie(ops, Bn, L, F, d, prec):
     """ops.wgrad_ta (the 16-bit features [B, L, F] as the k-major A operand of the per-layer decoder's weight-gradient GEMM)
-    gives the bits of ops.wgrad_t on the transposed copy, also accumulating; both against fp64."""
+    gives the bits of ops.wgrad_t on the transposed copy, also accumulating; both against fp64; bf16 and fp16 operands."""
+    from crosslayer_transcoder_amd import precision
     gen = torch.Generator().manual_seed(5)
-    feat = ops.cast_bf16(torch.relu(torch.randn(Bn, L, F, generator=gen)).cuda())
-    g = torch.randn(Bn, L, d, generator=gen).cuda()
-    gT = ops.transpose_cast_2d(g).view(L, d, Bn)
-    featT = feat.permute(1, 2, 0).contiguous()
-    assert ops.wgrad_ta_ok(Bn, F, d)
-    want = torch.einsum("blf,bld->lfd", feat.double().cpu(), gT.permute(2, 0, 1).double().cpu())
-    a = ops.wgrad_ta(feat, gT, torch.empty(L, F, d, device=DEV))
-    b = ops.wgrad_t(featT, gT, torch.empty(L, F, d, device=DEV), L, F * Bn, d * Bn)
-    assert torch.equal(a, b)
-    assert torch.allclose(a.double().cpu(), want, rtol=1e-4, atol=1e-3)
-    assert torch.equal(ops.wgrad_ta(feat, gT, a.clone(), True), ops.wgrad_t(featT, gT, b.clone(), L, F * Bn, d * Bn, True))
+    try:
+        with precision(prec):
+            ops.sync_operand_format()
+            feat = ops.cast_bf16(torch.relu(torch.randn(Bn, L, F, generator=gen)).cuda())
+            assert feat.dtype == (torch.float16 if prec == "16-mixed" else torch.bfloat16)
+            g = torch.randn(Bn, L, d, generator=gen).cuda()
+            gT = ops.transpose_cast_2d(g).view(L, d, Bn)
+            featT = feat.permute(1, 2, 0).contiguous()
+            assert ops.wgrad_ta_ok(Bn, F, d)
+            want = torch.einsum("blf,bld->lfd", feat.double().cpu(), gT.permute(2, 0, 1).double().cpu())
+            a = ops.wgrad_ta(feat, gT, torch.empty(L, F, d, device=DEV))
+            b = ops.wgrad_t(featT, gT, torch.empty(L, F, d, device=DEV), L, F * Bn, d * Bn)
+            assert torch.equal(a, b)
+            assert torch.allclose(a.double().cpu(), want, rtol=1e-4, atol=1e-3)
+            assert torch.equal(ops.wgrad_ta(feat, gT, a.clone(), True), ops.wgrad_t(featT, gT, b.clone(), L, F * Bn, d * Bn, True))
+    finally:
+        ops.sync_operand_format()
 
 
 @pytest.mark.parametrize("rows,L,F", [(64, 1, 256), (72, 2, 150), (200, 3, 64), (8, 1, 4), (136, 2, 1100)])
